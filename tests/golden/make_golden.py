@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate golden vectors by running the REFERENCE implementation (imported, unmodified).
+
+Run once in the build container (the reference never travels to the GPU box):
+
+    PYTHONPATH=/root/reference PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/make_golden.py
+
+Writes tests/golden/*.pt: plain dicts of tensors / lists / numbers (loadable with
+``torch.load(..., weights_only=True)``).  Only DATA is stored: inputs (token strings),
+injected noise, the reference's state_dict at tiny dims, and the reference's outputs.
+
+Harness-side adaptations (none touch reference files):
+  * ``nltk`` is stubbed in sys.modules (only PTBExample.parse_raw needs it) -- SURVEY 8c;
+  * ``torch.randn`` / ``torch.rand`` are wrapped to return queued tensors so that the latent
+    noise and the word-dropout draws are recorded and can be re-injected.
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+import numpy as np
+import torch
+import yaml
+
+REF = os.environ.get("DSSVAE_REFERENCE", "/root/reference")
+if REF not in sys.path:
+    sys.path.insert(0, REF)
+for name in ("nltk", "nltk.tree"):
+    m = types.ModuleType(name)
+    m.Tree = object
+    sys.modules.setdefault(name, m)
+
+from dss_vae.models import MODEL_CLS  # noqa: E402
+from dss_vae.structs.vocab import Vocab, VocabEntry  # noqa: E402
+from dss_vae.structs.dataset import PlainExample  # noqa: E402
+from dss_vae.utils.nn_funcs import kl_anneal_function, unk_replace, to_input_variable  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+torch.set_num_threads(4)
+torch.backends.mkldnn.enabled = True
+
+
+class NoiseTap:
+    """Replace torch.randn / torch.rand by a recorder with an optional replay queue."""
+
+    def __init__(self):
+        self.randn_log, self.rand_log = [], []
+        self._randn, self._rand = torch.randn, torch.rand
+        self.gen = torch.Generator().manual_seed(1)
+
+    def __enter__(self):
+        def randn(*size, **kw):
+            shape = size[0] if len(size) == 1 and not isinstance(size[0], int) else size
+            t = self._randn(list(shape), generator=self.gen)
+            self.randn_log.append(t.clone())
+            return t
+
+        def rand(*size, **kw):
+            shape = size[0] if len(size) == 1 and not isinstance(size[0], int) else size
+            t = self._rand(list(shape), generator=self.gen)
+            self.rand_log.append(t.clone())
+            return t
+
+        torch.randn, torch.rand = randn, rand
+        return self
+
+    def __exit__(self, *a):
+        torch.randn, torch.rand = self._randn, self._rand
+
+
+def make_vocab(n_src, n_tgt):
+    src, tgt = VocabEntry(), VocabEntry()
+    for i in range(n_src - 4):
+        src.add("w%d" % i)
+    for i in range(n_tgt - 4):
+        tgt.add("t%d" % i)
+    return Vocab(src=src, tgt=tgt)
+
+
+def make_examples(rng, B, n_src, n_tgt, max_src, tree_ratio=3, oov=True):
+    exs = []
+    for _ in range(B):
+        L = int(rng.integers(2, max_src + 1))
+        src = ["w%d" % int(rng.integers(0, n_src - 4)) for _ in range(L)]
+        if oov and L > 2:
+            src[1] = "OOV_TOKEN"
+        tgt = ["t%d" % int(rng.integers(0, n_tgt - 4)) for _ in range(tree_ratio * L)]
+        exs.append(PlainExample(src=src, tgt=tgt))
+    exs.sort(key=lambda e: -len(e.src))
+    return exs
+
+
+def base_args(model, dims):
+    cfg = "syntax-vae2.yaml" if model == "SyntaxVAE2" else "syntax-vae.yaml"
+    d = yaml.safe_load(open(os.path.join(REF, "configs/model_configs", cfg)))["model_configs"]
+    d.update(cuda=False, model_select=model)
+    d.update(dims)
+    return Namespace(**d)
+
+
+def t2l(x):
+    if isinstance(x, torch.Tensor):
+        return x.detach().clone()
+    return x
+
+
+def loss_dict(ret):
+    return {k: (t2l(v) if isinstance(v, torch.Tensor) else float(v)) for k, v in ret.items()}
+
+
+def ex_dump(exs):
+    return {"src": [list(e.src) for e in exs], "tgt": [list(e.tgt) for e in exs]}
+
+
+def run_case(tag, model_name, dims, B, n_src, n_tgt, max_src, seed, train_iter=6000):
+    rng = np.random.default_rng(seed)
+    torch.manual_seed(seed)
+    vocab = make_vocab(n_src, n_tgt)
+    args = base_args(model_name, dims)
+    model = MODEL_CLS[model_name](args=args, vocab=vocab)
+    g = torch.Generator().manual_seed(seed)
+    for p in model.parameters():
+        p.data.copy_(torch.empty(p.shape).uniform_(-0.08, 0.08, generator=g))
+    exs = make_examples(rng, B, n_src, n_tgt, max_src)
+    exs2 = make_examples(rng, B, n_src, n_tgt, max_src)
+    rng.shuffle(exs2)  # unsorted reference batch for eval_adv / eval_syntax (need_sort path)
+    exs2 = list(exs2)
+    out = {"model": model_name, "args": {k: v for k, v in vars(args).items()},
+           "n_src": n_src, "n_tgt": n_tgt, "examples": ex_dump(exs), "examples2": ex_dump(exs2),
+           "train_iter": train_iter, "torch": str(torch.__version__),
+           "state_dict": {k: v.clone() for k, v in model.state_dict().items()}}
+    positional = model_name == "VanillaVAE"
+
+    def get_loss(it, **kw):
+        return model.get_loss(exs, it) if positional else model.get_loss(exs, it, **kw)
+
+    # ---- eval mode: z = mean, no dropout -------------------------------------------------
+    model.eval()
+    with NoiseTap() as tap:
+        ret = get_loss(train_iter)
+    out["eval_loss"] = loss_dict(ret)
+    assert not tap.randn_log
+    out["eval_loss_warm"] = loss_dict(get_loss(10))
+    with torch.no_grad():
+        res = model.predict(exs)
+        out["predict_words"] = [r[0][0] for r in res]
+        # raw token matrix through the same calls predict() makes
+        r0 = model.encode_to_hidden(exs)
+        r0 = model.hidden_to_latent(ret=r0, is_sampling=False)
+        r0 = model.latent_for_init(ret=r0)
+        h0 = model.bridger.forward(input_tensor=r0["decode_init"])
+        _, _, rd, _ = model.decode(inputs=None, encoder_outputs=None, encoder_hidden=h0)
+        out["predict_tokens"] = torch.stack(rd["sequence"]).squeeze(-1).clone()
+        out["predict_lengths"] = list(rd["length"])
+        out["enc_hidden"] = r0["hidden"].clone()
+        out["decode_init"] = r0["decode_init"].clone()
+        # prior generation with recorded latent draws
+        with NoiseTap() as tap:
+            gen = model.generating(B, batch_size=B)
+        out["gen_eps"] = [t.clone() for t in tap.randn_log]
+        out["gen_words"] = [r[0][0] for r in gen]
+        if model_name != "VanillaVAE":
+            with NoiseTap() as tap:
+                cg = model.conditional_generating("sem", exs)
+            out["cond_sem_eps"] = [t.clone() for t in tap.randn_log]
+            out["cond_sem_words"] = [r[0][0] for r in cg["res"]]
+            with NoiseTap() as tap:
+                cg = model.conditional_generating("sem-only", exs)
+            out["cond_semonly_eps"] = [t.clone() for t in tap.randn_log]
+            out["cond_semonly_words"] = [r[0][0] for r in cg["res"]]
+        if model_name == "SyntaxVAE2":
+            adv = model.eval_adv(exs, exs2)
+            out["transfer_words"] = [r[0][0] for r in adv["res"]]
+            out["transfer_ori_syn"] = [r[0][0] for r in adv["ori syn"]]
+            out["transfer_ref_syn"] = [r[0][0] for r in adv["ref syn"]]
+            out["eval_syntax_words"] = [r[0][0] for r in model.eval_syntax(exs2)]
+        if model_name == "VanillaVAE":
+            adv = model.eval_adv(exs, exs2)
+            out["transfer_words"] = [r[0][0] for r in adv["res"]]
+
+    # ---- train mode, no dropout, injected eps; tgt_wd off and on ---------------------------
+    for wd in (False, True):
+        if wd and model_name == "VanillaVAE":
+            continue  # vanilla_vae.py:112 calls a method that does not exist
+        args.tgt_wd = wd
+        args.unk_rate = 0.4
+        model.train()
+        for p in model.parameters():
+            p.requires_grad = True
+        model.zero_grad()
+        with NoiseTap() as tap:
+            ret = get_loss(train_iter)
+        key = "train_wd" if wd else "train"
+        out[key + "_randn"] = [t.clone() for t in tap.randn_log]
+        out[key + "_rand"] = [t.clone() for t in tap.rand_log]
+        out[key + "_loss"] = loss_dict(ret)
+        torch.mean(ret["Loss"]).backward()
+        grads = {n: (p.grad.clone() if p.grad is not None else None) for n, p in model.named_parameters()}
+        out[key + "_grads"] = {n: g for n, g in grads.items() if g is not None}
+        out[key + "_nograd"] = [n for n, g in grads.items() if g is None]
+        out[key + "_gradnorm"] = float(torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values()
+                                                      if g is not None)))
+        if not positional:
+            for p in model.parameters():
+                p.requires_grad = True
+            with NoiseTap() as tap:
+                dret = model.get_loss(exs, train_iter, is_dis=True)
+            out[key + "_dis_randn"] = [t.clone() for t in tap.randn_log]
+            out[key + "_dis_rand"] = [t.clone() for t in tap.rand_log]
+            out[key + "_dis_syn"] = t2l(dret["dis syn"])
+            out[key + "_dis_sem"] = t2l(dret["dis sem"])
+            for p in model.parameters():
+                p.requires_grad = True
+    # before warm_up (SyntaxVAE2 drops the adversarial term, enhance_syntax_vae.py:333)
+    args.tgt_wd = False
+    model.zero_grad()
+    with NoiseTap() as tap:
+        ret = get_loss(10)
+    out["train_early_randn"] = [t.clone() for t in tap.randn_log]
+    out["train_early_loss"] = loss_dict(ret)
+    for p in model.parameters():
+        p.requires_grad = True
+
+    # ---- three optimisation steps (bin/train.py:84-88,119-126 restated) --------------------
+    model.load_state_dict(out["state_dict"])
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=0.0005, betas=(0.9, 0.995))
+    steps = []
+    with NoiseTap() as tap:
+        for it in range(train_iter + 1, train_iter + 4):
+            opt.zero_grad()
+            ret = get_loss(it)
+            torch.mean(ret["Loss"]).backward()
+            gn = torch.nn.utils.clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            steps.append({"loss": loss_dict(ret), "gradnorm": float(gn)})
+    out["steps"] = steps
+    out["steps_randn"] = [t.clone() for t in tap.randn_log]
+    out["steps_rand"] = [t.clone() for t in tap.rand_log]
+    out["steps_final_state"] = {k: v.clone() for k, v in model.state_dict().items()}
+    out["steps_requires_grad"] = {n: bool(p.requires_grad) for n, p in model.named_parameters()}
+    torch.save(out, os.path.join(OUT, tag + ".pt"))
+    print("wrote", tag, {k: (float(v) if not isinstance(v, torch.Tensor) or v.dim() == 0 else tuple(v.shape))
+                         for k, v in out["train_loss"].items()})
+
+
+def run_misc():
+    out = {}
+    rows = []
+    for fn in ("fixed", "logistic", "sigmoid", "negative-sigmoid", "linear"):
+        for step in (0, 1, 100, 2500, 5000, 7500, 20000):
+            rows.append((fn, step, float(kl_anneal_function(fn, step, 0.0025, 5000))))
+    out["anneal"] = rows
+    v = VocabEntry()
+    for i in range(20):
+        v.add("w%d" % i)
+    ids = to_input_variable([["w1", "w2", "zzz", "w3"], ["w4"], ["w5", "w6"]], v, training=False,
+                            append_boundary_sym=True, batch_first=True)
+    out["tensorise_ids"] = ids.clone()
+    with NoiseTap() as tap:
+        rep = unk_replace(ids, 0.5, v)
+    out["unk_rand"] = tap.rand_log[0].clone()
+    out["unk_out"] = rep.clone()
+    # packed bi-GRU encoder vs lengths (encoder/rnn_encoder.py:36-55)
+    from dss_vae.encoder import RNNEncoder
+    torch.manual_seed(3)
+    enc = RNNEncoder(vocab_size=24, max_len=10, input_size=12, hidden_size=10, n_layers=2, bidirectional=True,
+                     rnn_cell="gru", variable_lengths=True)
+    for p in enc.parameters():
+        p.data.uniform_(-0.3, 0.3)
+    ids = torch.randint(4, 24, (5, 7))
+    lens = [7, 6, 4, 2, 1]
+    for b, L in enumerate(lens):
+        ids[b, L:] = 0
+    o, h = enc.forward(ids, lens)
+    out["gru_state"] = {k: v.clone() for k, v in enc.state_dict().items()}
+    out["gru_ids"], out["gru_lens"], out["gru_out"], out["gru_hn"] = ids, lens, o.detach().clone(), h.detach().clone()
+    torch.save(out, os.path.join(OUT, "misc.pt"))
+    print("wrote misc")
+
+
+if __name__ == "__main__":
+    tiny = dict(embed_size=16, hidden_size=16, enc_embed_dim=16, enc_hidden_dim=16, dec_embed_dim=16,
+                dec_hidden_dim=16, latent_size=8, src_max_time_step=12, tgt_max_time_step=30,
+                enc_ed=0.0, enc_rd=0.0, dec_ed=0.0, dec_rd=0.0)
+    mid = dict(embed_size=20, hidden_size=60, enc_embed_dim=20, enc_hidden_dim=60, dec_embed_dim=20,
+               dec_hidden_dim=60, latent_size=12, src_max_time_step=10, tgt_max_time_step=24,
+               enc_ed=0.0, enc_rd=0.0, dec_ed=0.0, dec_rd=0.0)
+    run_misc()
+    for name in ("SyntaxVAE2", "SyntaxVAE", "VanillaVAE"):
+        run_case("%s_tiny" % name, name, dict(tiny), B=6, n_src=60, n_tgt=24, max_src=9, seed=11)
+        run_case("%s_mid" % name, name, dict(mid), B=5, n_src=90, n_tgt=30, max_src=7, seed=23)
