@@ -1,0 +1,38 @@
+// Shared helpers for the gfx950 (MI355X / CDNA4) kernels.  wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/dssvae_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define DSSVAE_CHECK_LAUNCH()                         \
+    do {                                              \
+        hipError_t e__ = hipGetLastError();           \
+        if (e__ != hipSuccess) return (int)e__;       \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// counter-based RNG (splitmix64 finaliser over (seed, index)); uniform in [0,1)
+__device__ __forceinline__ float u01(uint64_t seed, uint64_t idx) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ull * (idx + 1);
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    x = x ^ (x >> 31);
+    return (float)(x >> 40) * (1.0f / 16777216.0f);
+}
+
+// Bijective XCD-aware remap (blocks b and b+8 share an XCD under round-robin dispatch): each
+// XCD gets a contiguous chunk of the logical tile order, so neighbouring tiles share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, x = bid & 7, i = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+}

@@ -1,0 +1,223 @@
+// HBM-bound pointwise / reduction kernels (roofline: HBM3E ~8 TB/s spec, ~6.3 TB/s achievable):
+// embedding rows, dropout masks, word dropout, reparameterisation + KL (wavefront reduction),
+// GRU cell for the greedy loop, grad-norm and Adam over flat buffers.
+#include "common.h"
+
+namespace {
+
+__global__ void embed_gather_kernel(const float* __restrict__ table, int64_t ldt, const int64_t* __restrict__ ids,
+                                    int M, int E, const float* __restrict__ mask, float* __restrict__ out,
+                                    int64_t ldo) {
+    // one wave per row: 64 lanes x float4 cover 256 floats per trip, coalesced
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* src = table + ids[row] * ldt;
+    float* dst = out + (int64_t)row * ldo;
+    const float* mk = mask ? mask + (int64_t)row * E : nullptr;
+    for (int e = lane; e < E; e += 64) dst[e] = mk ? src[e] * mk[e] : src[e];
+}
+
+__global__ void embed_scatter_kernel(float* __restrict__ dtable, int64_t ldt, const int64_t* __restrict__ ids, int M,
+                                     int E, const float* __restrict__ mask, const float* __restrict__ g,
+                                     int64_t ldg) {
+    // one wave per row, 256 contiguous bytes per atomic wave-instruction (full atomic rate shape)
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int lane = threadIdx.x & 63;
+    float* dst = dtable + ids[row] * ldt;
+    const float* src = g + (int64_t)row * ldg;
+    const float* mk = mask ? mask + (int64_t)row * E : nullptr;
+    for (int e = lane; e < E; e += 64) atomicAdd(dst + e, mk ? src[e] * mk[e] : src[e]);
+}
+
+__global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, float scale, uint64_t seed) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = u01(seed, (uint64_t)i) < p ? 0.f : scale;
+}
+
+__global__ void unk_replace_kernel(const int64_t* __restrict__ ids, int64_t n, const float* __restrict__ rnd,
+                                   float rate, uint64_t seed, int64_t sos, int64_t pad, int64_t eos, int64_t unk,
+                                   int64_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int64_t v = ids[i];
+    const float r = rnd ? rnd[i] : u01(seed, (uint64_t)i);
+    const bool special = v == sos || v == pad || v == eos;
+    out[i] = (!special && r < rate) ? unk : v;
+}
+
+__global__ void reparam_kl_fwd_kernel(const float* __restrict__ mean, const float* __restrict__ logv,
+                                      const float* __restrict__ eps, int64_t n, float* __restrict__ z,
+                                      float* __restrict__ kl) {
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mean[i], lv = logv[i];
+        if (z) z[i] = eps ? eps[i] * __expf(0.5f * lv) + m : m;
+        acc += 1.f + lv - m * m - __expf(lv);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && kl) atomicAdd(kl, -0.5f * acc);
+}
+
+__global__ void reparam_kl_bwd_kernel(const float* __restrict__ mean, const float* __restrict__ logv,
+                                      const float* __restrict__ eps, const float* __restrict__ dz,
+                                      const float* __restrict__ dkl, int64_t n, float* __restrict__ dmean,
+                                      float* __restrict__ dlogv) {
+    const float gk = dkl ? dkl[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float m = mean[i], lv = logv[i];
+        const float g = dz ? dz[i] : 0.f;
+        dmean[i] = g + gk * m;
+        dlogv[i] = (eps ? g * eps[i] * 0.5f * __expf(0.5f * lv) : 0.f) + gk * 0.5f * (__expf(lv) - 1.f);
+    }
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                const float* __restrict__ h, int B, int H, float* __restrict__ hn) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H) return;
+    const int64_t b = i / H, u = i % H;
+    const float* a = gi + b * 3 * H;
+    const float* c = gh + b * 3 * H;
+    const float r = sigmoidf_(a[u] + c[u]);
+    const float z = sigmoidf_(a[H + u] + c[H + u]);
+    const float n = tanhf(a[2 * H + u] + r * c[2 * H + u]);
+    hn[i] = (1.f - z) * n + z * h[i];
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 v = g4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+}
+
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
+                            float bc2_sqrt, const float* __restrict__ sumsq, float max_norm,
+                            const float* __restrict__ live) {
+    float clip = 1.f;
+    if (sumsq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
+    const float step = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (live && live[i] == 0.f) continue;  // parameter had no gradient this step: Adam skips it
+        const float gi = g[i] * clip;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        p[i] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+    }
+}
+
+inline unsigned grid_for(int64_t n, int block = 256, int cap = 2048) {
+    int64_t g = (n + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+
+extern "C" int dssvae_abi_version(void) { return 1; }
+
+extern "C" int dssvae_device_cus(int* n) {
+    if (!n) return DSSVAE_EINVAL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, dev);
+    if (e != hipSuccess) return (int)e;
+    *n = prop.multiProcessorCount;
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_embed_gather(const float* table, int64_t ldt, const int64_t* ids, int M, int E,
+                                   const float* mask, float* out, int64_t ldo, void* stream) {
+    if (!table || !ids || !out || M <= 0 || E <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, table, ldt, ids, M,
+                       E, mask, out, ldo);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_embed_scatter_add(float* dtable, int64_t ldt, const int64_t* ids, int M, int E,
+                                        const float* mask, const float* g, int64_t ldg, void* stream) {
+    if (!dtable || !ids || !g || M <= 0 || E <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, dtable, ldt, ids,
+                       M, E, mask, g, ldg);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    if (!mask || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p,
+                       1.f / (1.f - p), seed);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_unk_replace(const int64_t* ids, int64_t n, const float* rnd, float rate, uint64_t seed,
+                                  int64_t sos, int64_t pad, int64_t eos, int64_t unk, int64_t* out, void* stream) {
+    if (!ids || !out || n <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(unk_replace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                       n, rnd, rate, seed, sos, pad, eos, unk, out);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_reparam_kl_fwd(const float* mean, const float* logv, const float* eps, int64_t n, float* z,
+                                     float* kl_out, void* stream) {
+    if (!mean || !logv || n <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(reparam_kl_fwd_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, mean,
+                       logv, eps, n, z, kl_out);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_reparam_kl_bwd(const float* mean, const float* logv, const float* eps, const float* dz,
+                                     const float* dkl, int64_t n, float* dmean, float* dlogv, void* stream) {
+    if (!mean || !logv || !dmean || !dlogv || n <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(reparam_kl_bwd_kernel, dim3(grid_for(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, mean,
+                       logv, eps, dz, dkl, n, dmean, dlogv);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_gru_cell(const float* gi, const float* gh, const float* h, int B, int H, float* h_new,
+                               void* stream) {
+    if (!gi || !gh || !h || !h_new || B <= 0 || H <= 0) return DSSVAE_EINVAL;
+    const int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(gru_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
+                       h, B, H, h_new);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_sumsq(const float* g, int64_t n, float* sumsq_out, void* stream) {
+    if (!g || !sumsq_out || n <= 0 || !aligned16(g)) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq_out);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                                float beta2, float eps, int step, const float* sumsq, float max_norm,
+                                const float* grad_scale_mask, void* stream) {
+    if (!p || !g || !m || !v || n <= 0 || step < 1) return DSSVAE_EINVAL;
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+                       beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}

@@ -1,0 +1,99 @@
+"""ctypes binding of the C-ABI in include/dssvae_hip.h (libdssvae_hip.so, built in-tree by
+``__graft_entry__.build()`` / ``make -C dss_vae_amd/csrc``).
+
+There is no fallback: if the library is missing, loading raises, and every op in
+``dss_vae_amd.ops`` refuses non-CUDA tensors.  PyTorch is used only for device memory and the
+current HIP stream; tensors cross the boundary as raw device pointers.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdssvae_hip.so")
+
+GRU_MAX_INST = 8
+E_TOOBIG = -2
+_ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
+           -3: "DSSVAE_ETIMEOUT (persistent kernel gave up waiting)"}
+
+
+class GruFwdInst(C.Structure):
+    _fields_ = [("xproj", C.c_void_p), ("ldx", C.c_int64), ("whh", C.c_void_p), ("bhh", C.c_void_p),
+                ("h0", C.c_void_p), ("lengths", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("h_last", C.c_void_p), ("gates", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32),
+                ("H", C.c_int32), ("reverse", C.c_int32)]
+
+
+class GruBwdInst(C.Structure):
+    _fields_ = [("whh", C.c_void_p), ("h0", C.c_void_p), ("lengths", C.c_void_p), ("out", C.c_void_p),
+                ("ldo", C.c_int64), ("gates", C.c_void_p), ("dout", C.c_void_p), ("ldd", C.c_int64),
+                ("dh_last", C.c_void_p), ("dgx", C.c_void_p), ("dgh", C.c_void_p), ("dh0", C.c_void_p),
+                ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32)]
+
+
+_P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+_SIGNATURES = {
+    "dssvae_abi_version": ([], _I),
+    "dssvae_device_cus": ([C.POINTER(C.c_int)], _I),
+    "dssvae_gemm_f32": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _P], _I),
+    "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P], _I),
+    "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
+    "dssvae_picked_logit": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _I, _P, _P], _I),
+    "dssvae_linear_ce_dlogits": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P], _I),
+    "dssvae_onehot_sub": ([_P, _L, _P, _I, _L, _P, _I, _I, _P], _I),
+    "dssvae_colsum": ([_P, _L, _I, _I, _P, _I, _P], _I),
+    "dssvae_embed_gather": ([_P, _L, _P, _I, _I, _P, _P, _L, _P], _I),
+    "dssvae_embed_scatter_add": ([_P, _L, _P, _I, _I, _P, _P, _L, _P], _I),
+    "dssvae_dropout_mask": ([_P, _L, _F, _U64, _P], _I),
+    "dssvae_unk_replace": ([_P, _L, _P, _F, _U64, _L, _L, _L, _L, _P, _P], _I),
+    "dssvae_reparam_kl_fwd": ([_P, _P, _P, _L, _P, _P, _P], _I),
+    "dssvae_reparam_kl_bwd": ([_P, _P, _P, _P, _P, _L, _P, _P, _P], _I),
+    "dssvae_gru_workspace_bytes": ([_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _L),
+    "dssvae_gru_fwd": ([C.POINTER(GruFwdInst), _I, _P, _L, _P], _I),
+    "dssvae_gru_bwd": ([C.POINTER(GruBwdInst), _I, _P, _L, _P], _I),
+    "dssvae_gru_check": ([_P, _P], _I),
+    "dssvae_gru_cell": ([_P, _P, _P, _I, _I, _P, _P], _I),
+    "dssvae_sumsq": ([_P, _L, _P, _P], _I),
+    "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P], _I),
+}
+EXPORTS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load the HIP library once; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "dss_vae_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C dss_vae_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        lib = C.CDLL(LIB_PATH)
+        for name, (argtypes, restype) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.argtypes, fn.restype = argtypes, restype
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed: %s" % (what, _ERRORS.get(rc, "hipError %d" % rc)))
+
+
+def ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("dss_vae_amd ops run on the MI355X only (got a %s tensor); there is no CPU path"
+                               % t.device)

@@ -1,0 +1,502 @@
+"""autograd wrappers over the C-ABI (include/dssvae_hip.h).  Every op launches hand-written HIP
+kernels on the current stream; torch is used for memory and tiny glue only.  No CPU path."""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import lib as L
+
+_CUS = None
+
+
+def n_cus():
+    global _CUS
+    if _CUS is None:
+        n = C.c_int(0)
+        L.check(L.load().dssvae_device_cus(C.byref(n)), "dssvae_device_cus")
+        _CUS = n.value
+    return _CUS
+
+
+def _f32(t):
+    if t.dtype != torch.float32:
+        raise RuntimeError("expected float32, got %s" % t.dtype)
+    return t
+
+
+def _rows(t):
+    """2-D view [R, C] with unit column stride -> (tensor, leading dimension)."""
+    assert t.dim() == 2 and (t.size(1) == 1 or t.stride(1) == 1), (t.shape, t.stride())
+    return t, (t.stride(0) if t.size(0) > 1 else max(t.stride(0), t.size(1)))
+
+
+# ----------------------------------------------------------------------------------------------
+# raw GEMM helpers (no autograd)
+# ----------------------------------------------------------------------------------------------
+def _gemm(A, lda, ta, B, ldb, tb, Cm, ldc, bias, M, N, K, alpha=1.0, beta=0.0, a_rows=None):
+    L.require_cuda(A, B, Cm)
+    L.check(L.load().dssvae_gemm_f32(L.ptr(A), lda, int(ta), L.ptr(a_rows), L.ptr(B), ldb, int(tb), L.ptr(Cm), ldc,
+                                     L.ptr(bias), M, N, K, alpha, beta, L.stream()), "dssvae_gemm_f32")
+
+
+def mm_nt(x, w, bias=None, out=None, beta=0.0):
+    """x[M,K] @ w[N,K]^T (+bias) -> [M,N]"""
+    x, ldx = _rows(_f32(x))
+    w, ldw = _rows(_f32(w))
+    M, K = x.shape
+    N = w.size(0)
+    assert w.size(1) == K
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    out, ldo = _rows(out)
+    if M and N:
+        _gemm(x, ldx, 0, w, ldw, 0, out, ldo, bias, M, N, K, 1.0, beta)
+    return out
+
+
+def mm_nn(dy, w, out=None, beta=0.0):
+    """dy[M,N] @ w[N,K] -> [M,K]"""
+    dy, ldy = _rows(_f32(dy))
+    w, ldw = _rows(_f32(w))
+    M, N = dy.shape
+    K = w.size(1)
+    assert w.size(0) == N
+    if out is None:
+        out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    out, ldo = _rows(out)
+    if M and K:
+        _gemm(dy, ldy, 0, w, ldw, 1, out, ldo, None, M, K, N, 1.0, beta)
+    return out
+
+
+def mm_tn(dy, x, out=None, beta=0.0):
+    """dy[M,N]^T @ x[M,K] -> [N,K]"""
+    dy, ldy = _rows(_f32(dy))
+    x, ldx = _rows(_f32(x))
+    M, N = dy.shape
+    K = x.size(1)
+    assert x.size(0) == M
+    if out is None:
+        out = torch.empty(N, K, device=dy.device, dtype=torch.float32)
+    out, ldo = _rows(out)
+    if N and K:
+        _gemm(dy, ldy, 1, x, ldx, 1, out, ldo, None, N, K, M, 1.0, beta)
+    return out
+
+
+def colsum(x, out=None, accumulate=False):
+    x, ldx = _rows(_f32(x))
+    M, N = x.shape
+    if out is None:
+        out = torch.empty(N, device=x.device, dtype=torch.float32)
+        accumulate = False
+    L.check(L.load().dssvae_colsum(L.ptr(x), ldx, M, N, L.ptr(out), int(accumulate), L.stream()), "dssvae_colsum")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Linear
+# ----------------------------------------------------------------------------------------------
+class _LinearFn(Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        L.require_cuda(x, w)
+        x2 = x.reshape(-1, x.size(-1))
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = b is not None
+        ctx.xshape = x.shape
+        return mm_nt(x2, w, b).view(*x.shape[:-1], w.size(0))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.size(-1)).contiguous()
+        dx = mm_nn(dy2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
+        dw = mm_tn(dy2, x2) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return dx, dw, db
+
+
+def linear(x, w, b=None):
+    return _LinearFn.apply(x, w, b)
+
+
+# ----------------------------------------------------------------------------------------------
+# Embedding rows (+ optional dropout mask)
+# ----------------------------------------------------------------------------------------------
+class _EmbedFn(Function):
+    @staticmethod
+    def forward(ctx, table, ids, mask):
+        L.require_cuda(table, ids)
+        flat = ids.reshape(-1).contiguous()
+        M, E = flat.numel(), table.size(1)
+        out = torch.empty(M, E, device=table.device, dtype=torch.float32)
+        L.check(L.load().dssvae_embed_gather(L.ptr(table), table.stride(0), L.ptr(flat), M, E, L.ptr(mask),
+                                             L.ptr(out), E, L.stream()), "dssvae_embed_gather")
+        ctx.save_for_backward(flat, mask)
+        ctx.tshape = table.shape
+        return out.view(*ids.shape, E)
+
+    @staticmethod
+    def backward(ctx, g):
+        flat, mask = ctx.saved_tensors
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        V, E = ctx.tshape
+        g2 = g.reshape(-1, E).contiguous()
+        dt = torch.zeros(V, E, device=g.device, dtype=torch.float32)
+        L.check(L.load().dssvae_embed_scatter_add(L.ptr(dt), E, L.ptr(flat), flat.numel(), E, L.ptr(mask),
+                                                  L.ptr(g2), E, L.stream()), "dssvae_embed_scatter_add")
+        return dt, None, None
+
+
+def embed(table, ids, mask=None):
+    return _EmbedFn.apply(table, ids, mask)
+
+
+def dropout_mask(shape, p, seed, device):
+    m = torch.empty(shape, device=device, dtype=torch.float32)
+    L.check(L.load().dssvae_dropout_mask(L.ptr(m), m.numel(), float(p), int(seed) & (2 ** 64 - 1), L.stream()),
+            "dssvae_dropout_mask")
+    return m
+
+
+def unk_replace(ids, rate, entry, rand=None, seed=0):
+    """word dropout on device (utils/nn_funcs.py:13-23)."""
+    if not rate > 0.0:
+        return ids
+    L.require_cuda(ids)
+    ids = ids.contiguous()
+    out = torch.empty_like(ids)
+    if rand is not None:
+        rand = rand.to(device=ids.device, dtype=torch.float32).contiguous()
+    L.check(L.load().dssvae_unk_replace(L.ptr(ids), ids.numel(), L.ptr(rand), float(rate), int(seed) & (2 ** 64 - 1),
+                                        entry.sos_id, entry.pad_id, entry.eos_id, entry.unk_id, L.ptr(out),
+                                        L.stream()), "dssvae_unk_replace")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Latent heads: reparameterisation + KL
+# ----------------------------------------------------------------------------------------------
+class _ReparamKLFn(Function):
+    @staticmethod
+    def forward(ctx, mean, logv, eps):
+        L.require_cuda(mean, logv)
+        mean, logv = mean.contiguous(), logv.contiguous()
+        eps = None if eps is None else eps.contiguous()
+        z = torch.empty_like(mean)
+        kl = torch.zeros((), device=mean.device, dtype=torch.float32)
+        L.check(L.load().dssvae_reparam_kl_fwd(L.ptr(mean), L.ptr(logv), L.ptr(eps), mean.numel(), L.ptr(z),
+                                               L.ptr(kl), L.stream()), "dssvae_reparam_kl_fwd")
+        ctx.save_for_backward(mean, logv, eps)
+        return z, kl
+
+    @staticmethod
+    def backward(ctx, dz, dkl):
+        mean, logv, eps = ctx.saved_tensors
+        dz = None if dz is None else dz.contiguous()
+        dkl = None if dkl is None else dkl.contiguous()
+        dm, dv = torch.empty_like(mean), torch.empty_like(logv)
+        L.check(L.load().dssvae_reparam_kl_bwd(L.ptr(mean), L.ptr(logv), L.ptr(eps), L.ptr(dz), L.ptr(dkl),
+                                               mean.numel(), L.ptr(dm), L.ptr(dv), L.stream()),
+                "dssvae_reparam_kl_bwd")
+        return dm, dv, None
+
+
+def reparam_kl(mean, logv, eps):
+    """-> (z, kl_sum); eps None => z = mean."""
+    return _ReparamKLFn.apply(mean, logv, eps)
+
+
+# ----------------------------------------------------------------------------------------------
+# Fused vocabulary projection + cross-entropy
+# ----------------------------------------------------------------------------------------------
+def _pick_split(M, N):
+    tiles_m, tiles_n = (M + 127) // 128, (N + 127) // 128
+    s = 1
+    while tiles_m * s < 2 * n_cus() and s * 2 <= tiles_n and s < 64:
+        s *= 2
+    return s
+
+
+def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False):
+    S = _pick_split(M, N)
+    dev = xh.device
+    pm = torch.empty(M, S, device=dev, dtype=torch.float32)
+    ps = torch.empty(M, S, device=dev, dtype=torch.float32)
+    pa = torch.empty(M, S, device=dev, dtype=torch.int64) if want_arg else None
+    lib = L.load()
+    L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
+                                      L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.stream()),
+            "dssvae_linear_lse_fwd")
+    lse = torch.empty(M, device=dev, dtype=torch.float32)
+    arg = torch.empty(M, device=dev, dtype=torch.int64) if want_arg else None
+    L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, L.ptr(lse), L.ptr(arg), L.stream()),
+            "dssvae_lse_combine")
+    return lse, arg
+
+
+SLAB_BYTES = 128 << 20  # row-chunk slab of dlogits: sized to stay inside the 256 MiB Infinity Cache
+
+
+class _LinearCEFn(Function):
+    """nll[m] = sum_t valid(m,t) * (lse[m] - logit[m, target[m,t]])  -- logits never materialised."""
+
+    @staticmethod
+    def forward(ctx, xh, xe, W, b, target, ignore_index):
+        L.require_cuda(xh, W, target)
+        xh, ldh = _rows(_f32(xh))
+        Kh = xh.size(1)
+        if xe is not None:
+            xe, lde = _rows(_f32(xe))
+            Ke = xe.size(1)
+        else:
+            lde, Ke = 0, 0
+        W, ldw = _rows(_f32(W))
+        M, N = xh.size(0), W.size(0)
+        assert W.size(1) == Kh + Ke
+        target = target.reshape(M, -1).contiguous()
+        T = target.size(1)
+        lse, _ = _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N)
+        picked = torch.empty(M, T, device=xh.device, dtype=torch.float32)
+        L.check(L.load().dssvae_picked_logit(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b),
+                                             L.ptr(target), T, int(ignore_index), M, L.ptr(picked), L.stream()),
+                "dssvae_picked_logit")
+        cnt = (target != ignore_index).sum(1).to(torch.float32)
+        ctx.save_for_backward(xh, xe, W, b, target, lse, cnt)
+        ctx.ignore = int(ignore_index)
+        return cnt * lse - picked.sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        xh, xe, W, b, target, lse, cnt = ctx.saved_tensors
+        need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
+        xh, ldh = _rows(xh)
+        Kh = xh.size(1)
+        if xe is not None:
+            xe, lde = _rows(xe)
+            Ke = xe.size(1)
+        else:
+            lde, Ke, need_xe = 0, 0, False
+        W, ldw = _rows(W)
+        M, N = xh.size(0), W.size(0)
+        T = target.size(1)
+        dev = xh.device
+        g = g.contiguous()
+        coef = (g * cnt).contiguous()
+        g_mt = g.unsqueeze(1).expand(M, T).contiguous()
+        ldd = (N + 3) // 4 * 4
+        rows = max(128, min((M + 127) // 128 * 128, (SLAB_BYTES // (ldd * 4)) // 128 * 128))
+        slab = torch.empty(min(rows, M), ldd, device=dev, dtype=torch.float32)
+        dxh = torch.empty(M, Kh, device=dev, dtype=torch.float32) if need_xh else None
+        dxe = torch.empty(M, Ke, device=dev, dtype=torch.float32) if need_xe else None
+        dW = torch.empty(N, Kh + Ke, device=dev, dtype=torch.float32) if need_w else None
+        db = torch.empty(N, device=dev, dtype=torch.float32) if (need_b and b is not None) else None
+        lib = L.load()
+        first = True
+        for m0 in range(0, M, rows):
+            mc = min(rows, M - m0)
+            xh_c = xh[m0:m0 + mc]
+            xe_c = xe[m0:m0 + mc] if xe is not None else None
+            dl = slab[:mc]
+            L.check(lib.dssvae_linear_ce_dlogits(L.ptr(xh_c), ldh, Kh, L.ptr(xe_c), lde, Ke, L.ptr(W), ldw, L.ptr(b),
+                                                 L.ptr(lse[m0:]), L.ptr(coef[m0:]), mc, N, L.ptr(dl), ldd,
+                                                 L.stream()), "dssvae_linear_ce_dlogits")
+            L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(g_mt[m0:]), mc, N,
+                                          L.stream()), "dssvae_onehot_sub")
+            dlv = dl[:, :N]
+            if need_xh:
+                mm_nn(dlv, W[:, :Kh], out=dxh[m0:m0 + mc])
+            if need_xe:
+                mm_nn(dlv, W[:, Kh:], out=dxe[m0:m0 + mc])
+            if need_w:
+                mm_tn(dlv, xh_c, out=dW[:, :Kh], beta=0.0 if first else 1.0)
+                if xe is not None:
+                    mm_tn(dlv, xe_c, out=dW[:, Kh:], beta=0.0 if first else 1.0)
+            if db is not None:
+                colsum(dlv, out=db, accumulate=not first)
+            first = False
+        return dxh, dxe, dW, db, None, None
+
+
+def linear_ce(xh, xe, W, b, target, ignore_index=0):
+    """-> per-row summed NLL [M]; xe may be None; target [M] or [M,T]."""
+    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index)
+
+
+def linear_argmax(xh, xe, W, b):
+    """argmax_n of the projection, fused (greedy decode; no logits materialised)."""
+    L.require_cuda(xh, W)
+    xh, ldh = _rows(_f32(xh))
+    if xe is not None:
+        xe, lde = _rows(_f32(xe))
+        Ke = xe.size(1)
+    else:
+        lde, Ke = 0, 0
+    W, ldw = _rows(W)
+    _, arg = _lse(xh, ldh, xh.size(1), xe, lde, Ke, W, ldw, b, xh.size(0), W.size(0), want_arg=True)
+    return arg
+
+
+# ----------------------------------------------------------------------------------------------
+# Persistent GRU
+# ----------------------------------------------------------------------------------------------
+def _pack(insts):
+    """Split instances into launches of <= 8 instances whose workgroups are co-resident."""
+    cus = n_cus()
+    launches, cur, wg = [], [], 0
+    for i, (B, H) in enumerate(insts):
+        need = ((B + 63) // 64) * ((H + 15) // 16)
+        if need > cus:
+            raise RuntimeError("GRU instance B=%d H=%d needs %d workgroups > %d CUs: not supported by the "
+                               "persistent kernel yet" % (B, H, need, cus))
+        if cur and (wg + need > cus or len(cur) == L.GRU_MAX_INST):
+            launches.append(cur)
+            cur, wg = [], 0
+        cur.append(i)
+        wg += need
+    if cur:
+        launches.append(cur)
+    return launches
+
+
+def _workspace(Bs, Hs, dev):
+    n = len(Bs)
+    nbytes = L.load().dssvae_gru_workspace_bytes(n, (C.c_int32 * n)(*Bs), (C.c_int32 * n)(*Hs))
+    if nbytes <= 0:
+        raise RuntimeError("dssvae_gru_workspace_bytes rejected the instance list")
+    return torch.empty(nbytes, device=dev, dtype=torch.uint8), nbytes
+
+
+def _xproj_ld(x):
+    B, T, G = x.shape
+    assert x.stride(2) == 1 and (B == 1 or x.stride(0) == T * x.stride(1)), (x.shape, x.stride())
+    return x.stride(1) if T > 1 else max(x.stride(1), G)
+
+
+class _GruFn(Function):
+    """meta = dict(n, group[], col[], reverse[], lengths, group_width[], save) ; tensors = per instance
+    (xproj, whh, bhh, h0-or-empty).  Returns (*group_outs, *h_last)."""
+
+    @staticmethod
+    def forward(ctx, meta, *tensors):
+        n = meta["n"]
+        xs, ws, bs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
+        L.require_cuda(*xs)
+        dev = xs[0].device
+        B, T = xs[0].size(0), xs[0].size(1)
+        Hs = [w.size(1) for w in ws]
+        lengths = meta["lengths"]
+        outs = [torch.empty(B, T, wdt, device=dev, dtype=torch.float32) for wdt in meta["group_width"]]
+        hl = [torch.empty(B, H, device=dev, dtype=torch.float32) for H in Hs]
+        save = meta["save"]
+        gates = [torch.empty(B, T, 5 * H, device=dev, dtype=torch.float32) if save else None for H in Hs]
+        ws = [w.contiguous() for w in ws]
+        bs = [b.contiguous() for b in bs]
+        h0s = [None if h.numel() == 0 else h.contiguous() for h in h0s]
+        lib = L.load()
+        for launch in _pack([(B, H) for H in Hs]):
+            arr = (L.GruFwdInst * len(launch))()
+            for k, i in enumerate(launch):
+                o = outs[meta["group"][i]]
+                arr[k] = L.GruFwdInst(
+                    xs[i].data_ptr(), _xproj_ld(xs[i]), ws[i].data_ptr(), bs[i].data_ptr(),
+                    None if h0s[i] is None else h0s[i].data_ptr(),
+                    None if lengths is None else lengths.data_ptr(),
+                    o.data_ptr() + 4 * meta["col"][i], o.size(2), hl[i].data_ptr(),
+                    None if gates[i] is None else gates[i].data_ptr(), B, T, Hs[i], int(meta["reverse"][i]))
+            wsb, nbytes = _workspace([B] * len(launch), [Hs[i] for i in launch], dev)
+            L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
+            if meta.get("check"):
+                L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
+        ctx.meta, ctx.Hs, ctx.BT = meta, Hs, (B, T)
+        ctx.h0_none = [h is None for h in h0s]
+        ctx.save_for_backward(*ws, *[h for h in h0s if h is not None], *[g for g in gates if g is not None])
+        return (*outs, *hl)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        meta, Hs, (B, T) = ctx.meta, ctx.Hs, ctx.BT
+        n = meta["n"]
+        ng = len(meta["group_width"])
+        saved = list(ctx.saved_tensors)
+        ws = saved[:n]
+        n_h0 = sum(1 for x in ctx.h0_none if not x)
+        gates = saved[n + n_h0:]
+        dev = ws[0].device
+        douts = [None if g is None else g.contiguous() for g in grads[:ng]]
+        dhl = [None if g is None else g.contiguous() for g in grads[ng:]]
+        lengths = meta["lengths"]
+        dgx = [torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32) for H in Hs]
+        dgh = [torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32) for H in Hs]
+        dh0 = [torch.empty(B, H, device=dev, dtype=torch.float32) for H in Hs]
+        lib = L.load()
+        for launch in _pack([(B, H) for H in Hs]):
+            arr = (L.GruBwdInst * len(launch))()
+            for k, i in enumerate(launch):
+                do = douts[meta["group"][i]]
+                arr[k] = L.GruBwdInst(
+                    ws[i].data_ptr(), None, None if lengths is None else lengths.data_ptr(), None, 0,
+                    gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
+                    0 if do is None else do.size(2), None if dhl[i] is None else dhl[i].data_ptr(),
+                    dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), B, T, Hs[i], int(meta["reverse"][i]))
+            wsb, nbytes = _workspace([B] * len(launch), [Hs[i] for i in launch], dev)
+            L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
+            if meta.get("check"):
+                L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
+        out = [None]
+        for i in range(n):
+            need = ctx.needs_input_grad[1 + 4 * i: 5 + 4 * i]
+            H = Hs[i]
+            g2 = dgh[i].view(B * T, 3 * H)
+            dw = mm_tn(g2, gates[i].view(B * T, 5 * H)[:, 4 * H:]) if need[1] else None
+            db = colsum(g2) if need[2] else None
+            out += [dgx[i] if need[0] else None, dw, db, dh0[i] if (need[3] and not ctx.h0_none[i]) else None]
+        return tuple(out)
+
+
+def gru_layer(insts, lengths=None, save=True, check=False):
+    """Run independent GRU recurrences in as few persistent launches as fit the chip.
+
+    insts: list of dicts {xproj [B,T,3H] (may be a column view), whh [3H,H], bhh [3H], h0 [B,H] or None,
+    reverse: bool, group: int, col: int}.  Instances of one group write disjoint column ranges
+    [col, col+H) of that group's output [B,T,width].  lengths: int32 device tensor [B] or None.
+    Returns (list of group outputs, list of per-instance final states)."""
+    n = len(insts)
+    groups = sorted(set(i["group"] for i in insts))
+    width = [0] * len(groups)
+    for i in insts:
+        g = groups.index(i["group"])
+        width[g] = max(width[g], i["col"] + i["whh"].size(1))
+    dev = insts[0]["xproj"].device
+    empty = torch.empty(0, device=dev)
+    meta = dict(n=n, group=[groups.index(i["group"]) for i in insts], col=[i["col"] for i in insts],
+                reverse=[bool(i.get("reverse", False)) for i in insts], lengths=lengths, group_width=width,
+                save=save, check=check)
+    flat = []
+    for i in insts:
+        flat += [i["xproj"], i["whh"], i["bhh"], empty if i.get("h0") is None else i["h0"]]
+    res = _GruFn.apply(meta, *flat)
+    return list(res[:len(groups)]), list(res[len(groups):])
+
+
+def gru_cell(gi, gh, h):
+    L.require_cuda(gi, gh, h)
+    out = torch.empty_like(h)
+    L.check(L.load().dssvae_gru_cell(L.ptr(gi.contiguous()), L.ptr(gh.contiguous()), L.ptr(h.contiguous()), h.size(0),
+                                     h.size(1), L.ptr(out), L.stream()), "dssvae_gru_cell")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# flat-buffer optimiser pieces
+# ----------------------------------------------------------------------------------------------
+def sumsq(flat, out):
+    L.check(L.load().dssvae_sumsq(L.ptr(flat), flat.numel(), L.ptr(out), L.stream()), "dssvae_sumsq")
+
+
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm):
+    L.check(L.load().dssvae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps, step,
+                                      L.ptr(sumsq_t), max_norm, None, L.stream()), "dssvae_adam_step")

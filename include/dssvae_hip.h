@@ -1,0 +1,180 @@
+/*
+ * dssvae_hip.h -- C-ABI of the MI355X (gfx950) hot path for DSS-VAE training / generation.
+ *
+ * Plain pointers and sizes only; every pointer is a DEVICE pointer unless the name ends in
+ * `_host`; `stream` is a hipStream_t passed as void*.  All matrices are fp32, row-major, with an
+ * explicit leading dimension (elements).  Token ids / targets are int64 (the reference's
+ * LongTensor).  Every entry point returns 0 on success, a negative DSSVAE_E* code on a
+ * rejected argument (nothing launched), or a positive hipError_t.  Nothing here allocates: the
+ * caller owns all buffers, workspaces included (sizes: dssvae_*_workspace_bytes).
+ *
+ * The reference (baoy-nlp/DSS-VAE) is pure Python on top of PyTorch ops; it has no FFI of its
+ * own for this path.  Each entry point therefore cites the reference call site (file:line under
+ * /root/reference) whose PyTorch op(s) it replaces; INTEGRATION.md shows the ctypes stub a
+ * reference maintainer would add at that call site.
+ */
+#ifndef DSSVAE_HIP_H
+#define DSSVAE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSSVAE_OK 0
+#define DSSVAE_EINVAL (-1)   /* bad shape / null pointer / misaligned leading dimension        */
+#define DSSVAE_ETOOBIG (-2)  /* persistent grid would not be co-resident / LDS budget exceeded */
+#define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
+
+/* library / device probing (no reference counterpart) */
+int dssvae_abi_version(void);
+int dssvae_device_cus(int* n_cus_host);
+
+/* ---------------------------------------------------------------------------------------------
+ * GEMM: C[M,N] = alpha * sum_k A(m,k) * B(n,k) + beta * C + bias[n]
+ *   trans_a = 0: A(m,k) = A[row(m)*lda + k]   (row(m) = a_rows ? a_rows[m] : m  -> fused gather)
+ *   trans_a = 1: A(m,k) = A[k*lda + m]
+ *   trans_b = 0: B(n,k) = B[n*ldb + k]        (nn.Linear weight [out,in])
+ *   trans_b = 1: B(n,k) = B[k*ldb + n]
+ * Replaces: the input half of nn.GRU for all timesteps (encoder/rnn_encoder.py:52,
+ * decoder/rnn_decoder.py:65), nn.Linear in hidden_to_latent / latent_for_init
+ * (vae/enhance_syntax_vae.py:433-436,451-452), and their autograd backward (dgrad / wgrad).
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_gemm_f32(const float* A, int64_t lda, int trans_a, const int64_t* a_rows,
+                    const float* B, int64_t ldb, int trans_b,
+                    float* C, int64_t ldc, const float* bias,
+                    int M, int N, int K, float alpha, float beta, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused vocabulary projection + online log-sum-exp (logits are never written).
+ *   logit[m,n] = Xh[m,:Kh] . W[n,:Kh] + Xe[m,:Ke] . W[n,Kh:Kh+Ke] + bias[n]
+ * dssvae_linear_lse_fwd writes, per row m and column split s (n_split of them), the running
+ * max and sum(exp(logit - max)) of that split into part_max/part_sum [M, n_split]; with
+ * want_argmax it also writes the split's best column into part_arg [M, n_split].
+ * Replaces: RNNDecoder.forward_step's `self.out(cat(output, embedded))` + F.log_softmax
+ * (decoder/rnn_decoder.py:70-73,94) and the scorer Linear+LogSoftmax of the bag-of-words heads
+ * (vae/enhance_syntax_vae.py:607-615).  Xe may be NULL (Ke = 0).
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                          const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
+                          float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
+                          void* stream);
+
+/* lse[m] = log sum_n exp(logit[m,n]) from the split partials; argmax[m] (may be NULL). */
+int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg,
+                       int M, int n_split, float* lse, int64_t* argmax, void* stream);
+
+/* picked[m,t] = logit[m, target[m,t]] (0 where target == ignore_index), T targets per row.
+ * Replaces torch.gather(log_scores, 1, tgt) (decoder/rnn_decoder.py:98) and the NLLLoss gather
+ * of bag_of_word_loss (utils/loss_funcs.py:117-129). */
+int dssvae_picked_logit(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                        const float* W, int64_t ldw, const float* bias, const int64_t* target, int T,
+                        int64_t ignore_index, int M, float* picked, void* stream);
+
+/* Backward, one row chunk: dL[m,n] = coef[m] * exp(logit[m,n] - lse[m]) for rows [0,M) of the
+ * chunk, written to the caller's slab dL [M, ldd] (ldd >= N).  The caller then subtracts the
+ * one-hot part (dssvae_onehot_sub) and runs dssvae_gemm_f32 for dX / dW / colsum for db.
+ * Replaces autograd of log_softmax+gather (decoder/rnn_decoder.py:94-102). */
+int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                             const float* W, int64_t ldw, const float* bias, const float* lse,
+                             const float* coef, int M, int N, float* dL, int64_t ldd, void* stream);
+
+/* dL[m, target[m,t]] -= g[m,t] for every non-ignored target (atomic: targets may repeat). */
+int dssvae_onehot_sub(float* dL, int64_t ldd, const int64_t* target, int T, int64_t ignore_index,
+                      const float* g, int M, int N, void* stream);
+
+/* out[n] (+)= sum_m X[m,n]  (bias gradients). */
+int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Embedding rows: out[m,:] = table[ids[m],:] * (mask ? mask[m,:] : 1)   (networks/embeddings.py:77-87)
+ * and its backward scatter-add dtable[ids[m],:] += g[m,:] * mask.
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_embed_gather(const float* table, int64_t ldt, const int64_t* ids, int M, int E,
+                        const float* mask, float* out, int64_t ldo, void* stream);
+int dssvae_embed_scatter_add(float* dtable, int64_t ldt, const int64_t* ids, int M, int E,
+                             const float* mask, const float* g, int64_t ldg, void* stream);
+
+/* Bernoulli keep-mask scaled by 1/(1-p) (nn.Dropout semantics), counter-based RNG. */
+int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream);
+
+/* Word dropout: ids -> unk where rand < rate, never on sos/pad/eos (utils/nn_funcs.py:13-23).
+ * `rand` NULL -> drawn on device from (seed). */
+int dssvae_unk_replace(const int64_t* ids, int64_t n, const float* rand, float rate, uint64_t seed,
+                       int64_t sos, int64_t pad, int64_t eos, int64_t unk, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Latent heads: z = eps * exp(0.5*logv) + mean ; kl_out[0] += -0.5*sum(1 + logv - mean^2 - e^logv)
+ * (vae/enhance_syntax_vae.py:417-424, vae/base_vae.py:198-201).  kl_out must be zeroed by the
+ * caller.  eps NULL -> z = mean (eval).  Backward: given dz and the scalar dkl,
+ * dmean = dz + dkl*mean ; dlogv = dz*eps*0.5*exp(0.5*logv) + dkl*0.5*(exp(logv)-1).
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_reparam_kl_fwd(const float* mean, const float* logv, const float* eps, int64_t n,
+                          float* z, float* kl_out, void* stream);
+int dssvae_reparam_kl_bwd(const float* mean, const float* logv, const float* eps, const float* dz,
+                          const float* dkl, int64_t n, float* dmean, float* dlogv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Persistent GRU recurrence (recurrent half of nn.GRU; encoder/rnn_encoder.py:52,
+ * decoder/rnn_decoder.py:65).  One launch runs up to DSSVAE_GRU_MAX_INST independent
+ * recurrences ("instances": directions / encoders / heads) concurrently on disjoint workgroups;
+ * W_hh slices stay resident in LDS for all T steps; gate math is fused; timesteps advance
+ * with per-(instance, batch-block) arrival counters (no grid-wide barrier).
+ *   xproj [B,T,ldx]  : x_t W_ih^T + b_ih for all t (gate order r,z,n), row stride ldx per (b,t)
+ *   whh [3H,H], bhh [3H], h0 [B,H] or NULL (zeros)
+ *   lengths [B] int32 or NULL: packed-sequence semantics (row b advances only while t < len[b];
+ *            `reverse` walks t = T-1..0; padded outputs are 0)
+ *   out [B,T,ldo]    : h_t (row stride ldo per (b,t), so two directions can interleave)
+ *   h_last [B,H]     : final state;  gates [B,T,5H]: r,z,n,(W_hn h + b_hn),h_{t-1} saved for
+ *                      backward (NULL in inference)
+ * sync: caller-provided workspace of dssvae_gru_workspace_bytes(...) bytes, need not be zeroed.
+ * ------------------------------------------------------------------------------------------- */
+#define DSSVAE_GRU_MAX_INST 8
+typedef struct {
+    const float* xproj; int64_t ldx;
+    const float* whh; const float* bhh; const float* h0;
+    const int32_t* lengths;
+    float* out; int64_t ldo;
+    float* h_last; float* gates;
+    int32_t B, T, H, reverse;
+} dssvae_gru_fwd_inst;
+
+typedef struct {
+    /* saved from forward */
+    const float* whh; const float* h0; const int32_t* lengths;
+    const float* out; int64_t ldo; const float* gates;
+    /* incoming gradients: dout [B,T,ldd] (or NULL), dh_last [B,H] (or NULL) */
+    const float* dout; int64_t ldd; const float* dh_last;
+    /* produced: dgx, dgh [B,T,3H] (grad wrt xproj / wrt W_hh h + b_hh), dh0 [B,H] */
+    float* dgx; float* dgh; float* dh0;
+    int32_t B, T, H, reverse;
+} dssvae_gru_bwd_inst;
+
+int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host);
+int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst_host, int n_inst, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst_host, int n_inst, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* Reads the error word a persistent launch leaves in its workspace (synchronises the stream). */
+int dssvae_gru_check(void* workspace, void* stream);
+
+/* One GRU cell step from precomputed gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (greedy loop,
+ * decoder/rnn_decoder.py:160-168): h_new = (1-z)*n + z*h. */
+int dssvae_gru_cell(const float* gi, const float* gh, const float* h, int B, int H, float* h_new,
+                    void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Optimiser over flat fp32 buffers (bin/train.py:124-126, utils/model_utils.py:195):
+ * sumsq_out[0] += sum(g^2);  Adam step with bias correction and the clip coefficient
+ * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) read on device (no host sync).
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_sumsq(const float* g, int64_t n, float* sumsq_out, void* stream);
+int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                     float beta2, float eps, int step, const float* sumsq, float max_norm,
+                     const float* grad_scale_mask, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSSVAE_HIP_H */

@@ -1,0 +1,230 @@
+"""Kernel-level parity (through the C-ABI, via dss_vae_amd.ops) against fp32/fp64 CPU math and the
+oracle's explicit GRU equations.  Tolerances: fp32 MFMA is an ordered fmaf chain, so results differ
+from a CPU BLAS only by summation order -> 2e-5 relative on O(1) values; losses 1e-5."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def close(a, b, rtol=2e-5, atol=2e-5, what=""):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    err = (a - b).abs().max().item() if a.numel() else 0.0
+    assert torch.allclose(a, b, rtol=rtol, atol=atol), (what, err)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 1, 1), (5, 7, 3), (128, 128, 32), (130, 257, 70), (256, 450, 150),
+                                   (300, 1800, 300), (64, 100, 600), (513, 64, 900)])
+def test_gemm_all_layouts(M, N, K):
+    from dss_vae_amd import ops
+    x, w, dy = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(M, N, seed=3)
+    b = rnd(N, seed=4)
+    xd, wd, dyd, bd = (t.to(DEV) for t in (x, w, dy, b))
+    close(ops.mm_nt(xd, wd, bd), x.double() @ w.double().t() + b.double(), what="nt")
+    close(ops.mm_nn(dyd, wd), dy.double() @ w.double(), what="nn")
+    close(ops.mm_tn(dyd, xd), dy.double().t() @ x.double(), what="tn")
+    # accumulate + strided views (leading dimension != width)
+    big = rnd(M, K + 5, seed=5).to(DEV)
+    xv = big[:, 2:2 + K]
+    out = torch.ones(M, N, device=DEV)
+    ops.mm_nt(xv, wd, None, out=out, beta=1.0)
+    close(out, xv.cpu().double() @ w.double().t() + 1.0, what="nt beta view")
+
+
+def test_gemm_row_gather():
+    from dss_vae_amd import ops
+    tab, w = rnd(50, 24, seed=1).to(DEV), rnd(36, 24, seed=2).to(DEV)
+    ids = torch.randint(0, 50, (77,), generator=torch.Generator().manual_seed(0)).to(DEV)
+    out = torch.empty(77, 36, device=DEV)
+    ops._gemm(tab, 24, 0, w, 24, 0, out, 36, None, 77, 36, 24, a_rows=ids)
+    close(out, tab[ids].cpu().double() @ w.cpu().double().t(), what="gather")
+
+
+def ce_reference(xh, xe, W, b, tgt, ignore):
+    x = xh if xe is None else torch.cat([xh, xe], 1)
+    logits = x.double() @ W.double().t() + b.double()
+    logp = torch.log_softmax(logits, -1)
+    tgt2 = tgt.reshape(x.size(0), -1)
+    tok = -logp.gather(1, tgt2) * (tgt2 != ignore)
+    return tok.sum(1)
+
+
+@pytest.mark.parametrize("M,Kh,Ke,N,T", [(7, 8, 4, 11, 1), (200, 60, 20, 300, 1), (300, 120, 20, 2000, 1),
+                                         (37, 16, 0, 515, 9), (256, 600, 0, 3001, 32), (130, 30, 18, 777, 1)])
+def test_linear_ce_forward_backward(M, Kh, Ke, N, T):
+    from dss_vae_amd import ops
+    g = torch.Generator().manual_seed(M + N)
+    xh, W, b = rnd(M, Kh, seed=1), rnd(N, Kh + Ke, seed=2, scale=0.3), rnd(N, seed=3, scale=0.1)
+    xe = rnd(M, Ke, seed=4) if Ke else None
+    tgt = torch.randint(0, N, (M, T), generator=g)
+    tgt[torch.rand(M, T, generator=g) < 0.3] = 0
+    tgt = tgt.squeeze(1) if T == 1 else tgt
+    gout = torch.rand(M, generator=g)
+    leaves = [t.clone().double().requires_grad_(True) if t is not None else None for t in (xh, xe, W, b)]
+    ref = ce_reference(*leaves, tgt, 0)
+    (ref * gout.double()).sum().backward()
+    dl = [t.clone().to(DEV).requires_grad_(True) if t is not None else None for t in (xh, xe, W, b)]
+    out = ops.linear_ce(dl[0], dl[1], dl[2], dl[3], tgt.to(DEV), 0)
+    close(out, ref, rtol=1e-5, atol=1e-4, what="nll")
+    (out * gout.to(DEV)).sum().backward()
+    for name, a, r in zip(("dxh", "dxe", "dW", "db"), dl, leaves):
+        if a is not None:
+            close(a.grad, r.grad, rtol=2e-4, atol=2e-5, what=name)
+
+
+def test_linear_ce_small_slab_chunks(monkeypatch):
+    """backward must give the same result when the dlogits slab forces many row chunks."""
+    from dss_vae_amd import ops
+    monkeypatch.setattr(ops, "SLAB_BYTES", 128 * 404 * 4)
+    test_linear_ce_forward_backward(300, 120, 20, 401, 1)
+
+
+def test_linear_argmax():
+    from dss_vae_amd import ops
+    xh, xe, W, b = rnd(50, 40, seed=1), rnd(50, 12, seed=2), rnd(3000, 52, seed=3), rnd(3000, seed=4)
+    ref = (torch.cat([xh, xe], 1).double() @ W.double().t() + b.double()).argmax(1)
+    got = ops.linear_argmax(xh.to(DEV), xe.to(DEV), W.to(DEV), b.to(DEV))
+    assert torch.equal(got.cpu(), ref)
+
+
+def test_embed_and_unk_replace_and_latent():
+    from dss_vae_amd import ops
+    import oracle
+    tab = rnd(40, 300, seed=1)
+    ids = torch.randint(0, 40, (6, 9), generator=torch.Generator().manual_seed(1))
+    mask = (torch.rand(6 * 9, 300) > 0.3).float() / 0.7
+    t = tab.clone().to(DEV).requires_grad_(True)
+    out = ops.embed(t, ids.to(DEV), mask.to(DEV))
+    close(out, tab[ids] * mask.view(6, 9, 300), what="embed")
+    gout = rnd(6, 9, 300, seed=2)
+    out.backward(gout.to(DEV))
+    ref = torch.zeros(40, 300).index_add_(0, ids.reshape(-1), (gout * mask.view(6, 9, 300)).reshape(-1, 300))
+    close(t.grad, ref, what="embed grad")
+    # word dropout with an injected uniform draw is bit-exact vs the oracle
+    ent = oracle.OVocabEntry("w%d" % i for i in range(30))
+    ids = torch.randint(0, 34, (5, 12), generator=torch.Generator().manual_seed(2))
+    r = torch.rand(5, 12, generator=torch.Generator().manual_seed(3))
+    assert torch.equal(ops.unk_replace(ids.to(DEV), 0.4, ent, rand=r).cpu(), oracle.word_dropout(ids, 0.4, ent, r))
+    assert ops.unk_replace(ids.to(DEV), 0.0, ent) is not None
+    frac = (ops.unk_replace(torch.full((1000, 50), 7, device=DEV), 0.25, ent, seed=9) == 3).float().mean().item()
+    assert abs(frac - 0.25) < 0.01
+    # reparameterisation + KL, forward and backward
+    mean, logv, eps = rnd(33, 100, seed=5), rnd(33, 100, seed=6), rnd(33, 100, seed=7)
+    m64, v64 = mean.double().requires_grad_(True), logv.double().requires_grad_(True)
+    z_ref = eps.double() * torch.exp(0.5 * v64) + m64
+    kl_ref = -0.5 * torch.sum(1 + v64 - m64.pow(2) - v64.exp())
+    gz = rnd(33, 100, seed=8)
+    ((z_ref * gz.double()).sum() + 0.37 * kl_ref).backward()
+    md, vd = mean.clone().to(DEV).requires_grad_(True), logv.clone().to(DEV).requires_grad_(True)
+    z, kl = ops.reparam_kl(md, vd, eps.to(DEV))
+    close(z, z_ref, what="z")
+    close(kl, kl_ref, rtol=1e-5, what="kl")
+    ((z * gz.to(DEV)).sum() + 0.37 * kl).backward()
+    close(md.grad, m64.grad, what="dmean")
+    close(vd.grad, v64.grad, what="dlogv")
+    z2, _ = ops.reparam_kl(md, vd, None)
+    close(z2, mean, what="z eval")
+    mk = ops.dropout_mask((1000, 300), 0.3, 5, DEV)
+    assert abs((mk == 0).float().mean().item() - 0.3) < 0.01 and abs(mk.max().item() - 1 / 0.7) < 1e-6
+
+
+def gru_reference(x, h0, wih, whh, bih, bhh, lengths, reverse):
+    import oracle
+    return oracle.gru_loop(x, h0, wih, whh, bih, bhh, lengths=lengths, reverse=reverse)
+
+
+@pytest.mark.parametrize("B,T,H,I,packed", [(3, 4, 8, 5, False), (70, 6, 30, 12, True), (64, 9, 150, 20, True),
+                                            (130, 5, 300, 16, False), (256, 4, 600, 8, False)])
+def test_persistent_gru_forward_backward(B, T, H, I, packed):
+    """two instances (forward + reverse direction) in one persistent launch, vs explicit equations"""
+    from dss_vae_amd import ops
+    g = torch.Generator().manual_seed(B + H)
+    lengths = None
+    if packed:
+        lengths = sorted([int(v) for v in torch.randint(1, T + 1, (B,), generator=g)], reverse=True)
+        lengths[0] = T
+    x = rnd(B, T, I, seed=1)
+    params, refs = [], []
+    for d in range(2):
+        p = [rnd(3 * H, I, seed=10 + d, scale=0.3), rnd(3 * H, H, seed=20 + d, scale=0.3),
+             rnd(3 * H, seed=30 + d, scale=0.3), rnd(3 * H, seed=40 + d, scale=0.3), rnd(B, H, seed=50 + d)]
+        params.append(p)
+    gout = rnd(B, T, 2 * H, seed=3)
+    ghl = [rnd(B, H, seed=60 + d) for d in range(2)]
+    # reference in fp64
+    leaves = [[t.clone().double().requires_grad_(True) for t in p] for p in params]
+    x64 = x.clone().double().requires_grad_(True)
+    outs, hls = [], []
+    for d in range(2):
+        wih, whh, bih, bhh, h0 = leaves[d]
+        o, h = gru_reference(x64, h0, wih, whh, bih, bhh, lengths, reverse=bool(d))
+        outs.append(o)
+        hls.append(h)
+    ref_out = torch.cat(outs, -1)
+    ((ref_out * gout.double()).sum() + sum((h * gg.double()).sum() for h, gg in zip(hls, ghl))).backward()
+    # device
+    dl = [[t.clone().to(DEV).requires_grad_(True) for t in p] for p in params]
+    xd = x.clone().to(DEV).requires_grad_(True)
+    len_d = None if lengths is None else torch.tensor(lengths, dtype=torch.int32, device=DEV)
+    insts = []
+    for d in range(2):
+        wih, whh, bih, bhh, h0 = dl[d]
+        xp = ops.linear(xd, wih, bih)
+        insts.append(dict(xproj=xp, whh=whh, bhh=bhh, h0=h0, reverse=bool(d), group=0, col=d * H))
+    (out,), hl = ops.gru_layer(insts, lengths=len_d, check=True)
+    close(out, ref_out, what="out")
+    for d in range(2):
+        close(hl[d], hls[d], what="h_last%d" % d)
+    ((out * gout.to(DEV)).sum() + sum((h * gg.to(DEV)).sum() for h, gg in zip(hl, ghl))).backward()
+    close(xd.grad, x64.grad, rtol=1e-4, atol=5e-5, what="dx")
+    for d in range(2):
+        for name, a, r in zip(("dwih", "dwhh", "dbih", "dbhh", "dh0"), dl[d], leaves[d]):
+            close(a.grad, r.grad, rtol=1e-4, atol=1e-4, what="%s[%d]" % (name, d))
+
+
+def test_gru_cell_and_no_h0():
+    from dss_vae_amd import ops
+    B, H = 50, 600
+    gi, gh, h = rnd(B, 3 * H, seed=1), rnd(B, 3 * H, seed=2), rnd(B, H, seed=3)
+    r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+    z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+    n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+    close(ops.gru_cell(gi.to(DEV), gh.to(DEV), h.to(DEV)), (1 - z) * n + z * h, what="cell")
+    # h0 = None means zeros; inference mode saves no gates
+    import oracle
+    x, whh, bhh = rnd(5, 3, 3 * 20, seed=4), rnd(60, 20, seed=5, scale=0.3), rnd(60, seed=6)
+    with torch.no_grad():
+        (out,), (hl,) = ops.gru_layer([dict(xproj=x.to(DEV), whh=whh.to(DEV), bhh=bhh.to(DEV), h0=None, group=0,
+                                            col=0)], save=False, check=True)
+    eye = torch.eye(60)
+    o, hT = oracle.gru_loop(x, torch.zeros(5, 20), eye, whh, torch.zeros(60), bhh)
+    close(out, o, what="out no h0")
+    close(hl, hT, what="hl no h0")
+
+
+def test_sumsq_and_adam():
+    from dss_vae_amd import ops
+    n = 100003
+    p, g = rnd(n, seed=1), rnd(n, seed=2, scale=3.0)
+    ref_p = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref_p], lr=5e-4, betas=(0.9, 0.995))
+    pd, m, v = p.clone().to(DEV), torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    for step in range(1, 4):
+        gs = g * step
+        ref_p.grad = gs.clone()
+        gn = torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+        opt.step()
+        gd = gs.to(DEV)
+        ss = torch.zeros(1, device=DEV)
+        ops.sumsq(gd, ss)
+        assert abs(ss.sqrt().item() - gn.item()) / gn.item() < 1e-5
+        ops.adam_step(pd, gd, m, v, 5e-4, 0.9, 0.995, 1e-8, step, ss, 5.0)
+    close(pd, ref_p, rtol=1e-5, atol=1e-6, what="adam")
