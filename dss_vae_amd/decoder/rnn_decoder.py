@@ -1,0 +1,165 @@
+"""RNNDecoder (reference: dss_vae/decoder/rnn_decoder.py:22-203; use_attention=False,
+use_last_output=True).  Teacher-forced scoring never materialises [B,T,V] logits: the
+``[h_t ; e_t] W_out^T`` projection is fused with an online log-sum-exp cross-entropy
+(ops.linear_ce); the per-step topk/.cpu() side work of rnn_decoder.py:132-144 is gone.
+``score_many`` runs several decoders (main decoder + task heads) layer by layer so that their
+recurrences share persistent GRU launches."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+from ..networks.embeddings import lookup
+from ..networks.rnn_base import GLOBAL_SEEDS, GRUParams, RNNBase
+
+
+class RNNDecoder(RNNBase):
+    KEY_ATTN_SCORE = "attention_score"
+    KEY_LENGTH = "length"
+    KEY_SEQUENCE = "sequence"
+
+    def __init__(self, vocab, max_len, input_size, hidden_size, eos_id, sos_id, pad_id=0, n_layers=1, rnn_cell="gru",
+                 embed_droprate=0, rnn_droprate=0, use_attention=False, embedding=None, update_embedding=True,
+                 use_last_output=True):
+        super().__init__(vocab, max_len, input_size, hidden_size, embed_droprate, rnn_droprate, n_layers, rnn_cell)
+        if use_attention or not use_last_output:
+            raise NotImplementedError("the VAE hot path forces use_attention=False (vae/enhance_syntax_vae.py:71) "
+                                      "and use_last_output=True")
+        self.rnn = GRUParams(input_size, hidden_size, n_layers, dropout=rnn_droprate)
+        self.max_length = max_len
+        self.use_attention, self.use_last_output = False, True
+        self.eos_id, self.sos_id, self.pad_id = eos_id, sos_id, pad_id
+        self.soft_input_size = hidden_size + input_size
+        self.out = nn.Linear(self.soft_input_size, self.vocab_size)
+        if embedding is not None:
+            self.embedding = embedding
+        self.embedding.weight.requires_grad = update_embedding
+
+    # ---- teacher-forced scoring (fused) ------------------------------------------------------
+    def score_inputs(self, inputs, targets, encoder_hidden, norm_by_word=False):
+        """log p(targets[:,1:] | inputs[:,:-1], h0) per sentence, [B]."""
+        return score_many([dict(dec=self, inputs=inputs, targets=targets, h0=encoder_hidden,
+                                norm_by_word=norm_by_word)])[0]
+
+    def score(self, inputs, encoder_hidden, encoder_outputs=None, norm_by_word=False):
+        return self.score_inputs(inputs, inputs, encoder_hidden, norm_by_word)
+
+    # ---- compatibility: materialised logits (not used by the model hot path) -------------------
+    def _features(self, ids, h0):
+        emb = lookup(self.embedding, ids, GLOBAL_SEEDS)
+        x, hl = emb, []
+        for layer in range(self.n_layers):
+            if layer > 0 and self.training and self.rnn_droprate > 0.0:
+                x = x * ops.dropout_mask(tuple(x.shape), self.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
+            wih, whh, bih, bhh = self.rnn.layer_params(layer)
+            (x,), (h,) = ops.gru_layer([dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=h0[layer],
+                                             group=0, col=0)], save=torch.is_grad_enabled())
+            hl.append(h)
+        return x, emb, torch.stack(hl, 0)
+
+    def forward_step(self, input_var, hidden, encoder_outputs=None, function=F.log_softmax):
+        out, emb, hidden = self._features(input_var, hidden)
+        logits = ops.linear(torch.cat((out, emb), dim=-1), self.out.weight, self.out.bias)
+        return function(logits, dim=-1), hidden, None
+
+    def decode(self, inputs, encoder_hidden, encoder_outputs=None, teacher_forcing_ratio=1.0):
+        """raw logits [T,B,V] (rnn_decoder.py:76-86).  Materialises; kept for interface parity only."""
+        out, emb, _ = self._features(inputs[:, :-1], encoder_hidden)
+        return ops.linear(torch.cat((out, emb), dim=-1), self.out.weight, self.out.bias).transpose(0, 1)
+
+    def score_decoding_results(self, scores, tgt_sents_var, norm_by_word=False):
+        B = scores.size(1)
+        if tgt_sents_var.size(0) == B:
+            tgt_sents_var = tgt_sents_var.contiguous().transpose(1, 0)
+        logp = F.log_softmax(scores.reshape(-1, scores.size(2)), dim=-1)
+        gold = tgt_sents_var[1:].contiguous().view(-1)
+        tok = torch.gather(logp, 1, gold.unsqueeze(1)).squeeze(1) * (1.0 - torch.eq(gold, self.pad_id).float())
+        tok = tok.view(-1, B).sum(dim=0)
+        if norm_by_word:
+            tok = tok.div(tgt_sents_var.transpose(1, 0).ne(self.pad_id).sum(dim=-1).float())
+        return tok
+
+    # ---- greedy generation ---------------------------------------------------------------------
+    @torch.no_grad()
+    def greedy_tokens(self, encoder_hidden, max_length=None):
+        """always max_length steps from <s> (rnn_decoder.py:160-168,193-199) -> int64 [max_len,B].
+        Per step: embedding rows, 2 small GEMMs + fused cell per layer, projection fused with argmax."""
+        max_length = self.max_length if max_length is None else max_length
+        B = encoder_hidden.size(1)
+        dev = encoder_hidden.device
+        tok = torch.full((B,), self.sos_id, dtype=torch.int64, device=dev)
+        h = [encoder_hidden[l].contiguous() for l in range(self.n_layers)]
+        params = [self.rnn.layer_params(l) for l in range(self.n_layers)]
+        table = self.embedding.weight
+        seq = torch.empty(max_length, B, dtype=torch.int64, device=dev)
+        for t in range(max_length):
+            emb = ops.embed(table, tok, None)
+            x = emb
+            for l, (wih, whh, bih, bhh) in enumerate(params):
+                h[l] = ops.gru_cell(ops.mm_nt(x, wih, bih), ops.mm_nt(h[l], whh, bhh), h[l])
+                x = h[l]
+            tok = ops.linear_argmax(x, emb, self.out.weight, self.out.bias)
+            seq[t] = tok
+        return seq, torch.stack(h, 0)
+
+    def forward(self, inputs=None, encoder_hidden=None, encoder_outputs=None, function=F.log_softmax,
+                teacher_forcing_ratio=0.0):
+        """Reference signature.  inputs=None -> greedy decode; the per-step [B,V] log-prob rows are NOT
+        materialised (decoder_outputs is empty), callers use ret_dict['sequence'] / ['length']."""
+        if inputs is not None and teacher_forcing_ratio > 0:
+            logits = self.decode(inputs, encoder_hidden)
+            outs = [function(logits[t], dim=-1) for t in range(logits.size(0))]
+            seq = [o.topk(1)[1] for o in outs]
+            return outs, None, {self.KEY_SEQUENCE: seq, self.KEY_LENGTH: self._lengths(torch.cat(seq, 1).t())}, \
+                encoder_hidden
+        if inputs is not None:
+            raise NotImplementedError("free-running decode from a given first column: pass inputs=None")
+        if encoder_hidden is None:
+            raise ValueError("encoder_hidden is required")
+        seq, hidden = self.greedy_tokens(encoder_hidden)
+        ret = {self.KEY_SEQUENCE: [seq[t].unsqueeze(1) for t in range(seq.size(0))], self.KEY_LENGTH: self._lengths(seq)}
+        return [], hidden, ret, encoder_hidden
+
+    def _lengths(self, seq):
+        """host bookkeeping of rnn_decoder.py:139-143: first </s> position + 1, else max length."""
+        T = seq.size(0)
+        hit = (seq == self.eos_id).cpu().numpy()
+        first = np.where(hit.any(0), hit.argmax(0) + 1, T)
+        return first.tolist()
+
+    def init_state(self, encoder_hidden):
+        return encoder_hidden
+
+
+def score_many(jobs):
+    """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word}.
+    -> list of per-sentence log-probabilities [B], one per job."""
+    n_layers = jobs[0]["dec"].n_layers
+    assert all(j["dec"].n_layers == n_layers for j in jobs)
+    embs, xs = [], []
+    for j in jobs:
+        e = lookup(j["dec"].embedding, j["inputs"][:, :-1].contiguous(), GLOBAL_SEEDS)
+        embs.append(e)
+        xs.append(e)
+    for layer in range(n_layers):
+        insts = []
+        for k, j in enumerate(jobs):
+            dec, x = j["dec"], xs[k]
+            if layer > 0 and dec.training and dec.rnn_droprate > 0.0:
+                x = x * ops.dropout_mask(tuple(x.shape), dec.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
+            wih, whh, bih, bhh = dec.rnn.layer_params(layer)
+            insts.append(dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=j["h0"][layer], group=k, col=0))
+        xs, _ = ops.gru_layer(insts, save=torch.is_grad_enabled())
+    res = []
+    for k, j in enumerate(jobs):
+        dec = j["dec"]
+        B, T, H = xs[k].shape
+        gold = j["targets"][:, 1:].reshape(-1)
+        nll = ops.linear_ce(xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1), dec.out.weight, dec.out.bias, gold,
+                            dec.pad_id)
+        logp = -nll.view(B, T).sum(1)
+        if j.get("norm_by_word"):
+            logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())
+        res.append(logp)
+    return res

@@ -1,0 +1,18 @@
+"""Model registry (reference: dss_vae/models/__init__.py:12-34).  Only the DSS-VAE family is on the
+MI355X hot path; the other research models of the reference repo are out of scope."""
+from ..vae.enhance_syntax_vae import EnhanceSyntaxVAE
+from ..vae.syntax_vae import SyntaxVAE
+from ..vae.vanilla_vae import VanillaVAE
+
+MODEL_CLS = {
+    "VanillaVAE": VanillaVAE,
+    "SyntaxVAE": SyntaxVAE,
+    "SyntaxVAE2": EnhanceSyntaxVAE,
+}
+
+
+def init_create_model(model: str, **kwargs):
+    if model not in MODEL_CLS:
+        raise ValueError("Invalid model class '{}' provided. Only {} are supported now.".format(
+            model, list(MODEL_CLS.keys())))
+    return MODEL_CLS[model](**kwargs)

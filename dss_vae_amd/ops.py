@@ -378,7 +378,8 @@ def _xproj_ld(x):
 
 class _GruFn(Function):
     """meta = dict(n, group[], col[], reverse[], lengths, group_width[], save) ; tensors = per instance
-    (xproj, whh, bhh, h0-or-empty).  Returns (*group_outs, *h_last)."""
+    (xproj, whh, bhh, h0-or-empty).  Instances may differ in B, T and H; instances of one output
+    group share B and T.  Returns (*group_outs, *h_last)."""
 
     @staticmethod
     def forward(ctx, meta, *tensors):
@@ -386,39 +387,45 @@ class _GruFn(Function):
         xs, ws, bs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
         L.require_cuda(*xs)
         dev = xs[0].device
-        B, T = xs[0].size(0), xs[0].size(1)
+        BT = [(x.size(0), x.size(1)) for x in xs]
         Hs = [w.size(1) for w in ws]
         lengths = meta["lengths"]
-        outs = [torch.empty(B, T, wdt, device=dev, dtype=torch.float32) for wdt in meta["group_width"]]
-        hl = [torch.empty(B, H, device=dev, dtype=torch.float32) for H in Hs]
+        outs = []
+        for g, wdt in enumerate(meta["group_width"]):
+            Bg, Tg = BT[meta["group"].index(g)]
+            outs.append(torch.empty(Bg, Tg, wdt, device=dev, dtype=torch.float32))
+        hl = [torch.empty(BT[i][0], H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
         save = meta["save"]
-        gates = [torch.empty(B, T, 5 * H, device=dev, dtype=torch.float32) if save else None for H in Hs]
+        gates = [torch.empty(BT[i][0], BT[i][1], 5 * H, device=dev, dtype=torch.float32) if save else None
+                 for i, H in enumerate(Hs)]
         ws = [w.contiguous() for w in ws]
         bs = [b.contiguous() for b in bs]
         h0s = [None if h.numel() == 0 else h.contiguous() for h in h0s]
         lib = L.load()
-        for launch in _pack([(B, H) for H in Hs]):
+        for launch in _pack([(BT[i][0], Hs[i]) for i in range(n)]):
             arr = (L.GruFwdInst * len(launch))()
             for k, i in enumerate(launch):
                 o = outs[meta["group"][i]]
+                assert (o.size(0), o.size(1)) == BT[i]
                 arr[k] = L.GruFwdInst(
                     xs[i].data_ptr(), _xproj_ld(xs[i]), ws[i].data_ptr(), bs[i].data_ptr(),
                     None if h0s[i] is None else h0s[i].data_ptr(),
                     None if lengths is None else lengths.data_ptr(),
                     o.data_ptr() + 4 * meta["col"][i], o.size(2), hl[i].data_ptr(),
-                    None if gates[i] is None else gates[i].data_ptr(), B, T, Hs[i], int(meta["reverse"][i]))
-            wsb, nbytes = _workspace([B] * len(launch), [Hs[i] for i in launch], dev)
+                    None if gates[i] is None else gates[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
+                    int(meta["reverse"][i]))
+            wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
-        ctx.meta, ctx.Hs, ctx.BT = meta, Hs, (B, T)
+        ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
         ctx.h0_none = [h is None for h in h0s]
         ctx.save_for_backward(*ws, *[h for h in h0s if h is not None], *[g for g in gates if g is not None])
         return (*outs, *hl)
 
     @staticmethod
     def backward(ctx, *grads):
-        meta, Hs, (B, T) = ctx.meta, ctx.Hs, ctx.BT
+        meta, Hs, BT = ctx.meta, ctx.Hs, ctx.BT
         n = meta["n"]
         ng = len(meta["group_width"])
         saved = list(ctx.saved_tensors)
@@ -429,11 +436,11 @@ class _GruFn(Function):
         douts = [None if g is None else g.contiguous() for g in grads[:ng]]
         dhl = [None if g is None else g.contiguous() for g in grads[ng:]]
         lengths = meta["lengths"]
-        dgx = [torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32) for H in Hs]
-        dgh = [torch.empty(B, T, 3 * H, device=dev, dtype=torch.float32) for H in Hs]
-        dh0 = [torch.empty(B, H, device=dev, dtype=torch.float32) for H in Hs]
+        dgx = [torch.empty(BT[i][0], BT[i][1], 3 * H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
+        dgh = [torch.empty(BT[i][0], BT[i][1], 3 * H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
+        dh0 = [torch.empty(BT[i][0], H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
         lib = L.load()
-        for launch in _pack([(B, H) for H in Hs]):
+        for launch in _pack([(BT[i][0], Hs[i]) for i in range(n)]):
             arr = (L.GruBwdInst * len(launch))()
             for k, i in enumerate(launch):
                 do = douts[meta["group"][i]]
@@ -441,8 +448,9 @@ class _GruFn(Function):
                     ws[i].data_ptr(), None, None if lengths is None else lengths.data_ptr(), None, 0,
                     gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
                     0 if do is None else do.size(2), None if dhl[i] is None else dhl[i].data_ptr(),
-                    dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), B, T, Hs[i], int(meta["reverse"][i]))
-            wsb, nbytes = _workspace([B] * len(launch), [Hs[i] for i in launch], dev)
+                    dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
+                    int(meta["reverse"][i]))
+            wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
@@ -450,8 +458,9 @@ class _GruFn(Function):
         for i in range(n):
             need = ctx.needs_input_grad[1 + 4 * i: 5 + 4 * i]
             H = Hs[i]
-            g2 = dgh[i].view(B * T, 3 * H)
-            dw = mm_tn(g2, gates[i].view(B * T, 5 * H)[:, 4 * H:]) if need[1] else None
+            rows = BT[i][0] * BT[i][1]
+            g2 = dgh[i].view(rows, 3 * H)
+            dw = mm_tn(g2, gates[i].view(rows, 5 * H)[:, 4 * H:]) if need[1] else None
             db = colsum(g2) if need[2] else None
             out += [dgx[i] if need[0] else None, dw, db, dh0[i] if (need[3] and not ctx.h0_none[i]) else None]
         return tuple(out)

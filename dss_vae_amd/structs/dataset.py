@@ -1,0 +1,57 @@
+"""Example / dataset containers in the reference's pickle layout (dss_vae/structs/dataset.py:37-122):
+``train.bin`` is a pickled *list* of PlainExample(src, tgt, idx, meta, entries)."""
+import pickle
+
+import numpy as np
+
+
+class PlainExample(object):
+    def __init__(self, src, tgt, idx=0, meta=None, **kwargs):
+        self.entries = []
+        for key, item in kwargs.items():
+            setattr(self, key, item)
+            self.entries.append(key)
+        self.src, self.tgt, self.idx, self.meta = src, tgt, idx, meta
+
+    @staticmethod
+    def parse_raw(raw_line, field_split="\t", token_split=" "):
+        items = raw_line.strip().split(field_split)
+        tgt = items[1].split(token_split) if len(items) > 1 else None
+        return PlainExample(src=items[0].split(token_split), tgt=tgt)
+
+    def __len__(self):
+        return len(self.src)
+
+
+def to_example(words, token_split=" "):
+    return PlainExample(src=words.split(token_split), tgt=None)
+
+
+class Dataset(object):
+    def __init__(self, examples):
+        self.examples = examples
+
+    @staticmethod
+    def from_bin_file(file_path):
+        with open(file_path, "rb") as f:
+            return Dataset(pickle.load(f))
+
+    @staticmethod
+    def from_list(raw_list):
+        return Dataset([PlainExample.parse_raw(line) for line in raw_list])
+
+    def batch_iter(self, batch_size, shuffle=False):
+        """shuffle, slice, sort each batch by -len(src) (packing needs descending lengths)."""
+        order = np.arange(len(self.examples))
+        if shuffle:
+            np.random.shuffle(order)
+        for lo in range(0, len(order), batch_size):
+            batch = [self.examples[i] for i in order[lo:lo + batch_size]]
+            batch.sort(key=lambda e: -len(e))
+            yield batch
+
+    def __len__(self):
+        return len(self.examples)
+
+    def __iter__(self):
+        return iter(self.examples)

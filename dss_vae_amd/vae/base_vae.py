@@ -1,0 +1,136 @@
+"""BaseVAE (reference: dss_vae/vae/base_vae.py:13-220) on the HIP ops.  Same public methods and
+``ret`` dict keys; ``self.noise`` is the RNG injection hook used by the parity tests (keys:
+eps / eps_syn / eps_sem / eps_syn_prior / rand_src / rand_tgt), absent keys are drawn on device."""
+import os
+
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..networks.rnn_base import GLOBAL_SEEDS
+from ..utils.nn_funcs import device, id2word, kl_anneal_function, to_input_variable, unk_replace
+
+
+class DeviceBatch(object):
+    """Pre-tensorised minibatch resident in HBM (kills the per-step Python tensorisation of
+    utils/nn_funcs.py:143-174).  Accepted wherever a list of examples is."""
+
+    def __init__(self, examples, vocab, with_tgt=True):
+        self.examples = examples
+        words = [e.src for e in examples]
+        self.length = [len(w) for w in words]
+        self.src = to_input_variable(words, vocab.src, batch_first=True)
+        self.tgt_var = to_input_variable(words, vocab.src, append_boundary_sym=True, batch_first=True)
+        self.syn_var = None
+        if with_tgt and examples[0].tgt is not None:
+            self.syn_var = to_input_variable([e.tgt for e in examples], vocab.tgt, append_boundary_sym=True,
+                                             batch_first=True)
+
+    def __len__(self):
+        return len(self.examples)
+
+
+class Linear(nn.Linear):
+    """nn.Linear parameters (same state_dict keys), MFMA GEMM forward/backward."""
+
+    def forward(self, x):
+        return ops.linear(x, self.weight, self.bias)
+
+
+class BaseVAE(nn.Module):
+    def __init__(self, args, vocab, name="Sentence VAE"):
+        super().__init__()
+        self.args, self.vocab, self.name = args, vocab, name
+        self.step_kl_weight = args.init_step_kl_weight
+        self.noise = {}
+
+    def base_information(self):
+        a = self.args
+        return "layers:{}\ntypes:{}\nembed:{}\nhidden:{}\nlatent:{}\nkl_factor:{}\nunk_rate:{}\nx0:{}\n".format(
+            a.num_layers, a.rnn_type, a.embed_size, a.hidden_size, a.latent_size, a.kl_factor, a.unk_rate, a.x0)
+
+    # ---- noise ---------------------------------------------------------------------------------
+    def _randn(self, key, shape):
+        v = self.noise.get(key)
+        if v is not None:
+            return v.to(device(), dtype=torch.float32)
+        return torch.randn(shape, device=device())
+
+    def _word_dropout(self, ids, key):
+        return unk_replace(ids, self.step_unk_rate, self.vocab.src, rand=self.noise.get(key),
+                           seed=GLOBAL_SEEDS.next())
+
+    # ---- batches ---------------------------------------------------------------------------------
+    def _batch(self, examples, with_tgt=True):
+        if isinstance(examples, DeviceBatch):
+            return examples
+        if not isinstance(examples, list):
+            examples = [examples]
+        return DeviceBatch(examples, self.vocab, with_tgt=with_tgt)
+
+    def predict(self, examples, to_word=True):
+        ret = self.encode_to_hidden(examples)
+        ret = self.hidden_to_latent(ret=ret, is_sampling=self.training)
+        ret = self.latent_for_init(ret=ret)
+        return self.decode_to_sentence(ret=ret)
+
+    def generating(self, sample_num, batch_size=50):
+        batch_size = batch_size if sample_num >= batch_size else sample_num
+        res = []
+        for _ in range(int((sample_num - 1) / batch_size) + 1):
+            res.extend(self.decode_to_sentence(self.latent_for_init(self.sample_latent(batch_size))))
+        return res
+
+    unsupervised_generating = generating
+
+    def encode_to_hidden(self, examples, need_sort=False, **kwargs):
+        batch = self._batch(examples, with_tgt=False)
+        B = len(batch)
+        if not need_sort:
+            _, hidden = self.encode(input_var=batch.src, length=batch.length)
+            return {"outputs": None, "hidden": hidden, "length": batch.length, "batch_size": B}
+        lens = batch.length
+        order = sorted(range(B), key=lambda i: -lens[i])
+        back = [0] * B
+        for new, old in enumerate(order):
+            back[old] = new
+        idx = torch.as_tensor(order, device=batch.src.device)
+        ids = batch.src.index_select(0, idx)
+        if self.training and self.args.src_wd:
+            ids = self._word_dropout(ids, "rand_src")
+        _, hidden = self.encode(ids, [lens[i] for i in order])
+        bidx = torch.as_tensor(back, device=hidden.device)
+        hidden = hidden.index_select(1, bidx) if hidden.dim() > 2 else hidden.index_select(0, bidx)
+        return {"outputs": None, "hidden": hidden, "length": lens, "batch_size": B}
+
+    def decode_tokens(self, ret):
+        """greedy token matrix [max_len,B] (device) for the sentence decoder."""
+        h0 = self.bridger.forward(input_tensor=ret["decode_init"])
+        return self.decoder.greedy_tokens(h0)[0]
+
+    def decode_to_sentence(self, ret):
+        toks = self.decode_tokens(ret).t().tolist()
+        out = []
+        for hyp in toks:
+            res = id2word(hyp, self.vocab.src)
+            out.append([[res], [len(res)]])
+        return out
+
+    def get_kl_weight(self, step):
+        if self.step_kl_weight is None:
+            return kl_anneal_function(self.args.anneal_function, step, self.args.k, self.args.x0)
+        return self.step_kl_weight
+
+    def compute_kl_loss(self, mean, logv, step):
+        """standalone KL (base_vae.py:198-201); the models fuse it with the reparameterisation."""
+        _, kl = ops.reparam_kl(mean, logv, None)
+        return kl, self.get_kl_weight(step)
+
+    def save(self, path):
+        d = os.path.dirname(path)
+        if d and not os.path.exists(d):
+            os.makedirs(d)
+        if not os.path.exists(path + ".config"):
+            with open(path + ".config", "w") as f:
+                f.write("{}".format(self.base_information()))
+        torch.save({"args": self.args, "vocab": self.vocab, "state_dict": self.state_dict()}, path)

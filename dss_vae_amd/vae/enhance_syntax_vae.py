@@ -1,0 +1,145 @@
+"""EnhanceSyntaxVAE, registry key 'SyntaxVAE2' (reference: dss_vae/vae/enhance_syntax_vae.py:47-637).
+Scalar head losses; adversary parameters are frozen through requires_grad (the reference's
+detach()/reload(), :573-579) so gradient reaches the latents but not the adversaries; the -adv term
+enters 'Loss' only when train_iter > warm_up (:333)."""
+import torch
+
+from ..decoder.rnn_decoder import score_many
+from ..utils.nn_funcs import wd_anneal_function
+from .syntax_vae import BridgeMLP, BridgeRNN, TwoEncoderVAE
+
+
+class RNNPredictor(BridgeRNN):
+    def forward(self, hidden, tgt_var, div_by_word=False):
+        job = self.job(hidden, tgt_var)
+        job["norm_by_word_len"] = div_by_word
+        return -_finish(job, score_many([job])[0]).sum()
+
+    def detach(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def reload(self):
+        for p in self.parameters():
+            p.requires_grad = True
+
+
+def _finish(job, logp):
+    if job.get("norm_by_word_len"):
+        logp = logp.div(job["targets"].ne(job["dec"].pad_id).sum(-1).float() + 1e-9)
+    return logp
+
+
+class MLPPredictor(BridgeMLP):
+    def forward(self, hidden, tgt_var, div_by_word=False):
+        loss = self.per_sentence(hidden, tgt_var)
+        if div_by_word:
+            loss = loss.div(1e-9 + tgt_var.ne(self.pad_id).sum(-1).float())
+        return loss.sum()
+
+    def detach(self):
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def reload(self):
+        for p in self.parameters():
+            p.requires_grad = True
+
+
+class EnhanceSyntaxVAE(TwoEncoderVAE):
+    ENC_NAMES = ("sem_encoder", "syn_encoder")
+    ADVERSARIES = ("sem_to_sent", "syn_to_sent", "syn_to_sem", "sem_to_syn")
+
+    def __init__(self, args, vocab, src_embed=None, tgt_embed=None):
+        super().__init__(args, vocab, name="Syntax VAE with 2 seperate encoder")
+        self._build_common(args, vocab, src_embed, tgt_embed)
+        self.pad_idx = vocab.src.pad_id
+        te, td = self.task_enc_dim, self.task_dec_dim
+        share = args.share_embed
+        self.mul_syn = RNNPredictor(args, vocab, te, td, tgt_embed, "tgt")
+        self.mul_sem = MLPPredictor(args, vocab, te, td)
+        self.sem_to_syn = RNNPredictor(args, vocab, te, td, self.tgt_embed if share else None, "tgt")
+        self.syn_to_sem = MLPPredictor(args, vocab, te, td)
+        self.sem_to_sent = RNNPredictor(args, vocab, te, td, self.src_embed if share else None, "src")
+        self.syn_to_sent = RNNPredictor(args, vocab, te, td, self.src_embed if share else None, "src")
+
+    def _adv_jobs(self, syn_h, sem_h, syn_tgt, sem_tgt):
+        a = self.args
+        jobs, names = [], []
+        if a.sem_to_syn > 0.0:
+            jobs.append(self.sem_to_syn.job(sem_h, syn_tgt)); names.append("sem_to_syn")
+        if a.sem_to_sent > 0.0:
+            jobs.append(self.sem_to_sent.job(sem_h, sem_tgt)); names.append("sem_to_sent")
+        if a.syn_to_sent > 0.0:
+            jobs.append(self.syn_to_sent.job(syn_h, sem_tgt)); names.append("syn_to_sent")
+        return jobs, names
+
+    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=()):
+        a = self.args
+        jobs, names = self._adv_jobs(syn_h, sem_h, syn_tgt, sem_tgt)
+        res = score_many(list(extra_jobs) + jobs) if (jobs or extra_jobs) else []
+        ne = len(extra_jobs)
+        d = {"sem_to_syn": 0.0, "sem_to_sent": 0.0, "syn_to_sent": 0.0,
+             "syn_to_sem": self.syn_to_sem.forward(hidden=syn_h, tgt_var=sem_tgt) if a.syn_to_sem > 0.0 else 0.0}
+        for n, r in zip(names, res[ne:]):
+            d[n] = -r.sum()
+        return d, res[:ne]
+
+    def forward(self, examples, is_dis=False, norm_by_word=False):
+        batch, ret = self._front(examples)
+        tgt_var, syn_var = batch.tgt_var, batch.syn_var
+        syn_h, sem_h = ret["syn_hidden"], ret["sem_hidden"]
+        a = self.args
+        if is_dis:
+            for n in self.ADVERSARIES:
+                getattr(self, n).reload()
+            d, _ = self._dis_terms(syn_h.detach(), sem_h.detach(), syn_var, tgt_var)
+            if a.infer_weight > 0.0:
+                ret["dis syn"] = d["syn_to_sem"] + d["syn_to_sent"]
+                ret["dis sem"] = d["sem_to_syn"] + d["sem_to_sent"]
+            else:
+                ret["dis syn"], ret["dis sem"] = d["syn_to_sem"], d["sem_to_syn"]
+            return ret
+        # same order as the reference: main decoder + multitask heads are recorded first, THEN the
+        # adversaries are frozen (this also flips requires_grad of the shared src/tgt embeddings, a
+        # reference quirk pinned by the golden 'nograd' lists), then the adversaries run.
+        main_jobs = [self._main_job(ret, tgt_var), self.mul_syn.job(syn_h, syn_var)]
+        rec, tree = score_many(main_jobs)
+        mul_sem_loss = a.mul_sem * self.mul_sem.forward(hidden=sem_h, tgt_var=tgt_var)
+        if self.training:
+            for n in self.ADVERSARIES:
+                getattr(self, n).detach()
+        d, _ = self._dis_terms(syn_h, sem_h, syn_var, tgt_var)
+        if a.infer_weight > 0.0:
+            adv_for_syn = a.syn_to_sem * d["syn_to_sem"] + a.infer_weight * a.syn_to_sent * d["syn_to_sent"]
+            adv_for_sem = a.sem_to_syn * d["sem_to_syn"] + a.infer_weight * a.sem_to_sent * d["sem_to_sent"]
+        else:
+            adv_for_syn, adv_for_sem = a.syn_to_sem * d["syn_to_sem"], a.sem_to_syn * d["sem_to_syn"]
+        mul_syn_loss = a.mul_syn * (-tree).sum()
+        ret["adv"], ret["mul"] = adv_for_syn + adv_for_sem, mul_syn_loss + mul_sem_loss
+        ret["nll_loss"] = (-rec).sum()
+        ret["sem_loss"], ret["syn_loss"], ret["batch_size"] = mul_sem_loss, mul_syn_loss, len(batch)
+        return ret
+
+    def get_loss(self, examples, train_iter, is_dis=False, **kwargs):
+        a = self.args
+        self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, train_iter, a.k, a.x0)
+        explore = self.forward(examples, is_dis, norm_by_word=False)
+        if is_dis:
+            return explore
+        sem_kl, syn_kl, kl_loss, kl_weight = self._kl_terms(explore, train_iter)
+        B = explore["batch_size"]
+        kl_loss = kl_loss / B
+        mul_loss, adv_loss, nll_loss = explore["mul"] / B, explore["adv"] / B, explore["nll_loss"] / B
+        kl_item = kl_loss * kl_weight
+        loss = kl_item + nll_loss + mul_loss - adv_loss if train_iter > a.warm_up else kl_item + nll_loss + mul_loss
+        return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
+                "KL Weight": kl_weight, "KL Item": kl_item, "Model Score": kl_loss + nll_loss,
+                "ELBO": kl_item + nll_loss, "Loss": loss, "SYN KL Loss": syn_kl / B, "SEM KL Loss": sem_kl / B}
+
+    def eval_syntax(self, examples):
+        ret = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(examples, need_sort=True), False))
+        return self.predict_syntax(hidden=ret["syn_hidden"], predictor=self.mul_syn)
+
+    def eval_adv(self, sem_in, syn_ref):
+        return self._transfer(sem_in, syn_ref, self.mul_syn)

@@ -1,0 +1,291 @@
+"""SyntaxVAE and its task heads (reference: dss_vae/vae/syntax_vae.py:50-602) on the HIP ops.
+
+Reference quirks that are part of the contract and kept: the tree-decoder head returns a
+per-sentence [B] vector (syntax_vae.py:547-556) so 'MUL Loss' / 'ADV Loss' / 'Loss' are [B]
+vectors; the adversaries run under no_grad in train mode (:322-324)."""
+import torch
+import torch.nn as nn
+
+from .. import ops
+from ..decoder.rnn_decoder import RNNDecoder, score_many
+from ..encoder.rnn_encoder import RNNEncoder, encode_many
+from ..networks.bridger import MLPBridger
+from ..networks.rnn_base import GLOBAL_SEEDS
+from ..utils.nn_funcs import id2word, wd_anneal_function
+from .base_vae import BaseVAE, Linear
+
+
+class BridgeRNN(nn.Module):
+    """bridger + sequence decoder head; forward -> per-sentence NLL [B]."""
+
+    def __init__(self, args, vocab, enc_hidden_dim, dec_hidden_dim, embed, mode="src"):
+        super().__init__()
+        self.bridger = MLPBridger(args.rnn_type, args.mapper_type, enc_hidden_dim, args.enc_num_layers,
+                                  dec_hidden_dim, args.dec_num_layers)
+        ent = vocab.src if mode == "src" else vocab.tgt
+        self.decoder = RNNDecoder(
+            vocab=len(ent), max_len=args.src_max_time_step if mode == "src" else args.tgt_max_time_step,
+            input_size=args.dec_embed_dim, hidden_size=dec_hidden_dim, embed_droprate=args.dec_ed,
+            rnn_droprate=args.dec_rd, n_layers=args.dec_num_layers, rnn_cell=args.rnn_type,
+            use_attention=args.use_attention, embedding=embed, eos_id=ent.eos_id, sos_id=ent.sos_id)
+        self.pad_id = ent.pad_id
+
+    def job(self, hidden, tgt_var):
+        return dict(dec=self.decoder, inputs=tgt_var, targets=tgt_var, h0=self.bridger.forward(input_tensor=hidden))
+
+    def forward(self, hidden, tgt_var):
+        return -score_many([self.job(hidden, tgt_var)])[0]
+
+    def predict(self, hidden):
+        return self.decoder.greedy_tokens(self.bridger.forward(input_tensor=hidden))[0]
+
+
+class BridgeMLP(nn.Module):
+    """bridger + bag-of-words scorer (Dropout -> Linear -> LogSoftmax -> NLL over all non-pad
+    tokens incl. <s>, </s>), fused: one LSE per sentence, no [B*T,V] expansion."""
+
+    def __init__(self, args, vocab, enc_dim, dec_hidden):
+        super().__init__()
+        self.bridger = MLPBridger(args.rnn_type, args.mapper_type, enc_dim, args.enc_num_layers, dec_hidden,
+                                  args.dec_num_layers)
+        self.scorer = nn.Sequential(nn.Dropout(args.dec_rd),
+                                    nn.Linear(dec_hidden * args.dec_num_layers, len(vocab.src), bias=True),
+                                    nn.LogSoftmax(dim=-1))
+        self.pad_id = vocab.src.pad_id
+        self.p = float(args.dec_rd)
+
+    def per_sentence(self, hidden, tgt_var):
+        B = tgt_var.size(0)
+        feat = self.bridger.forward(input_tensor=hidden).permute(1, 0, 2).contiguous().view(B, -1)
+        if self.training and self.p > 0.0:
+            feat = feat * ops.dropout_mask(tuple(feat.shape), self.p, GLOBAL_SEEDS.next(), feat.device)
+        lin = self.scorer[1]
+        return ops.linear_ce(feat, None, lin.weight, lin.bias, tgt_var, self.pad_id)
+
+    def forward(self, hidden, tgt_var):
+        return self.per_sentence(hidden, tgt_var).sum()
+
+
+class TwoEncoderVAE(BaseVAE):
+    """shared body of SyntaxVAE / EnhanceSyntaxVAE: two half-width bi-GRU encoders, semantic +
+    syntactic latents, main sentence decoder."""
+
+    ENC_NAMES = ("word_encoder", "syntax_encoder")
+
+    def _build_common(self, args, vocab, src_embed=None, tgt_embed=None):
+        self.src_embed = nn.Embedding(len(vocab.src), args.embed_size) if src_embed is None else src_embed
+        self.tgt_embed = nn.Embedding(len(vocab.tgt), args.embed_size) if tgt_embed is None else tgt_embed
+        self.latent_size = int(args.latent_size)
+        self.rnn_type = args.rnn_type
+        self.unk_rate = args.unk_rate
+        self.step_unk_rate = 0.0
+        self.direction_num = 2 if args.bidirectional else 1
+        self.enc_hidden_dim = args.enc_hidden_dim
+        self.enc_layer_dim = args.enc_hidden_dim * self.direction_num
+        self.enc_hidden_factor = self.direction_num * args.enc_num_layers
+        self.dec_hidden_factor = args.dec_num_layers
+        args.use_attention = False
+        self.dec_layer_dim = self.enc_layer_dim if args.mapper_type == "link" else args.dec_hidden_dim
+        var_dim = int(self.enc_hidden_dim * self.enc_hidden_factor / 2)
+        self.task_enc_dim, self.task_dec_dim = int(self.enc_layer_dim / 2), int(self.dec_layer_dim / 2)
+        for name in self.ENC_NAMES:
+            setattr(self, name, RNNEncoder(
+                vocab_size=len(vocab.src), max_len=args.src_max_time_step, input_size=args.enc_embed_dim,
+                hidden_size=int(self.enc_hidden_dim / 2), embed_droprate=args.enc_ed, rnn_droprate=args.enc_rd,
+                n_layers=args.enc_num_layers, bidirectional=args.bidirectional, rnn_cell=args.rnn_type,
+                variable_lengths=True, embedding=self.src_embed))
+        pack = BridgeRNN(args, vocab, self.enc_layer_dim, self.dec_layer_dim,
+                         self.src_embed if args.share_embed else None, "src")
+        self.bridger, self.decoder = pack.bridger, pack.decoder
+        self.syn_mean, self.syn_logv = Linear(var_dim, self.latent_size), Linear(var_dim, self.latent_size)
+        self.syn_to_h = Linear(self.latent_size, var_dim)
+        self.sem_mean, self.sem_logv = Linear(var_dim, self.latent_size), Linear(var_dim, self.latent_size)
+        self.sem_to_h = Linear(self.latent_size, var_dim)
+
+    def decode(self, inputs, encoder_outputs, encoder_hidden):
+        return self.decoder.forward(inputs=inputs, encoder_outputs=encoder_outputs, encoder_hidden=encoder_hidden)
+
+    def encode(self, input_var, length):
+        if self.training and self.args.src_wd > 0.0:
+            input_var = self._word_dropout(input_var, "rand_src")
+        (_, ha), (_, hb) = encode_many([getattr(self, n) for n in self.ENC_NAMES], input_var, length)
+        B = ha.size(1)
+        return None, torch.cat([ha.permute(1, 0, 2).contiguous().view(B, -1),
+                                hb.permute(1, 0, 2).contiguous().view(B, -1)], dim=-1)
+
+    def hidden_to_latent(self, ret, is_sampling=True):
+        hid = ret["hidden"]
+        B = hid.size(0)
+        halves = hid.contiguous().view(B, 2, -1)
+        sem_h, syn_h = halves[:, 0, :], halves[:, 1, :]
+        ret["syn_mean"], ret["syn_logv"] = self.syn_mean(syn_h), self.syn_logv(syn_h)
+        ret["sem_mean"], ret["sem_logv"] = self.sem_mean(sem_h), self.sem_logv(sem_h)
+        e_syn = self._randn("eps_syn", [B, self.latent_size]) if is_sampling else None  # syntax eps first
+        e_sem = self._randn("eps_sem", [B, self.latent_size]) if is_sampling else None
+        ret["syn_z"], ret["syn_kl"] = ops.reparam_kl(ret["syn_mean"], ret["syn_logv"], e_syn)
+        ret["sem_z"], ret["sem_kl"] = ops.reparam_kl(ret["sem_mean"], ret["sem_logv"], e_sem)
+        return ret
+
+    def sample_latent(self, batch_size):
+        return {"syn_z": self._randn("eps_syn", [batch_size, self.latent_size]),
+                "sem_z": self._randn("eps_sem", [batch_size, self.latent_size])}
+
+    def latent_for_init(self, ret):
+        B = ret["sem_z"].size(0)
+
+        def lay(x):
+            return x.view(B, self.enc_hidden_factor, int(self.enc_hidden_dim / 2)).permute(1, 0, 2)
+
+        ret["syn_hidden"] = lay(self.syn_to_h(ret["syn_z"]))
+        ret["sem_hidden"] = lay(self.sem_to_h(ret["sem_z"]))
+        ret["decode_init"] = torch.cat([ret["syn_hidden"], ret["sem_hidden"]], dim=-1)
+        return ret
+
+    def _front(self, examples):
+        batch = self._batch(examples)
+        ret = self.encode_to_hidden(batch)
+        ret = self.hidden_to_latent(ret=ret, is_sampling=self.training)
+        ret = self.latent_for_init(ret=ret)
+        return batch, ret
+
+    def _main_job(self, ret, tgt_var):
+        inputs = tgt_var
+        if self.training and self.args.tgt_wd:
+            inputs = self._word_dropout(tgt_var, "rand_tgt")
+        return dict(dec=self.decoder, inputs=inputs, targets=tgt_var,
+                    h0=self.bridger.forward(ret["decode_init"]))
+
+    def _kl_terms(self, ret, step):
+        a = self.args
+        w = self.get_kl_weight(step) * a.kl_factor
+        kl = (a.sem_weight * ret["sem_kl"] + a.syn_weight * ret["syn_kl"]) / (a.sem_weight + a.syn_weight)
+        return ret["sem_kl"], ret["syn_kl"], kl, w
+
+    def evaluate_(self, examples, beam_size=5):
+        batch, ret = self._front(examples)
+        ret["res"] = self.decode_to_sentence(ret=ret)
+        return ret
+
+    def predict_syntax(self, hidden, predictor):
+        toks = predictor.predict(hidden).t().tolist()
+        out = []
+        for hyp in toks:
+            res = id2word(hyp, self.vocab.tgt)
+            out.append([[res], [len(res)]])
+        return out
+
+    def conditional_generating(self, condition="sem", examples=None):
+        ret = self.hidden_to_latent(self.encode_to_hidden(examples), is_sampling=True)
+        if condition.startswith("sem"):
+            ret["sem_z"] = ret["sem_mean"]
+        else:
+            ret["syn_z"] = ret["syn_mean"]
+        if condition == "sem-only":
+            ret["syn_z"] = self._randn("eps_syn_prior", [ret["batch_size"], self.latent_size])
+        ret = self.latent_for_init(ret=ret)
+        ret["res"] = self.decode_to_sentence(ret=ret)
+        return ret
+
+    def _transfer(self, sem_in, syn_ref, predictor):
+        sem_ret = self.hidden_to_latent(self.encode_to_hidden(sem_in), is_sampling=self.training)
+        syn_ret = self.hidden_to_latent(self.encode_to_hidden(syn_ref, need_sort=True), is_sampling=self.training)
+        sem_ret, syn_ret = self.latent_for_init(ret=sem_ret), self.latent_for_init(ret=syn_ret)
+        ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
+        ret["res"] = self.decode_to_sentence(ret=ret)
+        ret["ori syn"] = self.predict_syntax(hidden=sem_ret["syn_hidden"], predictor=predictor)
+        ret["ref syn"] = self.predict_syntax(hidden=syn_ret["syn_hidden"], predictor=predictor)
+        return ret
+
+
+class SyntaxVAE(TwoEncoderVAE):
+    ENC_NAMES = ("word_encoder", "syntax_encoder")
+
+    def __init__(self, args, vocab, src_embed=None, tgt_embed=None):
+        super().__init__(args, vocab, name="Syntax VAE")
+        self._build_common(args, vocab, src_embed, tgt_embed)
+        self.pad_idx = vocab.src.sos_id
+        te, td = self.task_enc_dim, self.task_dec_dim
+        share = args.share_embed
+        self.sup_syn = BridgeRNN(args, vocab, te, td, tgt_embed, "tgt")
+        self.sup_sem = BridgeMLP(args, vocab, te, td)
+        self.syn_adv = BridgeRNN(args, vocab, te, td, self.tgt_embed if share else None, "tgt")
+        self.syn_infer = BridgeRNN(args, vocab, te, td, self.src_embed if share else None, "src")
+        self.sem_adv = BridgeMLP(args, vocab, te, td)
+        self.sem_infer = BridgeRNN(args, vocab, te, td, self.src_embed if share else None, "src")
+
+    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=()):
+        """the four adversary heads; sequence heads share persistent launches (plus extra_jobs,
+        whose log-probs are returned last)."""
+        a = self.args
+        jobs, names = [], []
+        if a.adv_syn > 0.0:
+            jobs.append(self.syn_adv.job(sem_h, syn_tgt)); names.append("adv_syn_sup")
+        if a.infer_weight > 0.0:
+            if a.inf_syn > 0.0:
+                jobs.append(self.syn_infer.job(syn_h, sem_tgt)); names.append("adv_syn_inf")
+            if a.inf_sem > 0.0:
+                jobs.append(self.sem_infer.job(sem_h, sem_tgt)); names.append("adv_sem_inf")
+        res = score_many(jobs + list(extra_jobs)) if jobs or extra_jobs else []
+        d = {"adv_syn_sup": 0.0, "adv_sem_sup": self.sem_adv(syn_h, sem_tgt) if a.adv_sem > 0.0 else 0.0}
+        if a.infer_weight > 0.0:
+            d.update(adv_syn_inf=0.0, adv_sem_inf=0.0)
+        for n, r in zip(names, res):
+            d[n] = -r
+        return d, res[len(names):]
+
+    def _adv_weights(self, d):
+        a = self.args
+        if a.infer_weight > 0.0:
+            return (a.adv_syn * d["adv_syn_sup"] + a.infer_weight * a.inf_sem * d["adv_sem_inf"],
+                    a.adv_sem * d["adv_sem_sup"] + a.infer_weight * a.inf_syn * d["adv_syn_inf"])
+        return a.adv_syn * d["adv_syn_sup"], a.adv_sem * d["adv_sem_sup"]
+
+    def forward(self, examples, is_dis=False):
+        batch, ret = self._front(examples)
+        tgt_var, syn_var = batch.tgt_var, batch.syn_var
+        syn_h, sem_h = ret["syn_hidden"], ret["sem_hidden"]
+        if is_dis:
+            d, _ = self._dis_terms(syn_h.detach(), sem_h.detach(), syn_var, tgt_var)
+            if self.args.infer_weight > 0.0:
+                ret["dis syn"] = d["adv_syn_sup"] + d["adv_sem_inf"]
+                ret["dis sem"] = d["adv_sem_sup"] + d["adv_syn_inf"]
+            else:
+                ret["dis syn"], ret["dis sem"] = d["adv_syn_sup"], d["adv_sem_sup"]
+            return ret
+        main_jobs = [self._main_job(ret, tgt_var), self.sup_syn.job(syn_h, syn_var)]
+        if self.training:
+            rec, tree = score_many(main_jobs)
+            with torch.no_grad():
+                d, _ = self._dis_terms(syn_h, sem_h, syn_var, tgt_var)
+        else:
+            d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs)
+        adv_syn, adv_sem = self._adv_weights(d)
+        mul_syn = self.args.mul_syn * (-tree)
+        mul_sem = self.args.mul_sem * self.sup_sem(sem_h, tgt_var)
+        ret["adv"], ret["mul"] = adv_syn + adv_sem, mul_syn + mul_sem
+        ret["nll_loss"] = -torch.sum(rec)
+        ret["sem_loss"], ret["syn_loss"], ret["batch_size"] = mul_sem, mul_syn, len(batch)
+        return ret
+
+    def get_loss(self, examples, train_iter, is_dis=False, **kwargs):
+        a = self.args
+        self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, train_iter, a.k, a.x0)
+        explore = self.forward(examples, is_dis)
+        if is_dis:
+            return explore
+        sem_kl, syn_kl, kl_loss, kl_weight = self._kl_terms(explore, train_iter)
+        B = explore["batch_size"]
+        kl_loss = kl_loss / B
+        mul_loss, adv_loss, nll_loss = explore["mul"] / B, explore["adv"] / B, explore["nll_loss"] / B
+        kl_item = kl_loss * kl_weight
+        return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
+                "KL Weight": kl_weight, "KL Item": kl_item, "Model Score": kl_loss + nll_loss,
+                "ELBO": kl_item + nll_loss, "Loss": kl_item + nll_loss + mul_loss - adv_loss,
+                "SYN KL Loss": syn_kl / B, "SEM KL Loss": sem_kl / B}
+
+    def eval_syntax(self, examples):
+        ret = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(examples, need_sort=True), False))
+        return self.predict_syntax(hidden=ret["syn_hidden"], predictor=self.sup_syn)
+
+    def eval_adv(self, sem_in, syn_ref):
+        return self._transfer(sem_in, syn_ref, self.sup_syn)
