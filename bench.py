@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""bench.py -- train sentences/sec (fwd+bwd+clip+Adam) of the full DSS-VAE on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[1], SURVEY 8d "C2"): full DSS-VAE (registry key SyntaxVAE2 =
+EnhanceSyntaxVAE: semantic + syntactic latents, linearised-tree decoder, BoW + adversarial heads),
+vocab 30000 / tree vocab 300, batch 256 per GPU, src len 30, tree len 90, default dims of the shipped
+yaml (E=H=300, 2-layer bi-GRU, Z=100), dropout as in the yaml, train_iter past warm_up so that the
+adversarial term is in the loss.  One step = zero_grad -> get_loss -> mean(Loss).backward() ->
+(gradient all-reduce over RCCL when N>1) -> global-norm clip 5.0 -> Adam, all in fp32.
+Inputs are tensorised once and are resident in HBM before the timed region.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step, its launches timed
+live with HIP events on the stream they run on; `kernels` lists the other hot kernels the same way;
+`cpu_baseline` is the CPU oracle (oracle/, the restatement of the reference pinned by the golden
+vectors) timed on this box's host cores on a bounded sample of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = fp32 vector peak
+PEAK_HBM_GBS = 8000.0         # HBM3E spec; ~6.3 TB/s achievable
+
+KERNEL_BOUND = {
+    "linear_lse_kernel": "mfma", "linear_dlogits_kernel": "mfma", "gemm_store_kernel": "mfma",
+    "gru_fwd_kernel": "hbm", "gru_bwd_kernel": "hbm", "adam_kernel": "hbm",
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="SyntaxVAE2", choices=["SyntaxVAE2", "SyntaxVAE", "VanillaVAE"])
+    ap.add_argument("--batch", type=int, default=256, help="sentences per GPU")
+    ap.add_argument("--vocab", type=int, default=30000)
+    ap.add_argument("--tree-vocab", type=int, default=300)
+    ap.add_argument("--src-len", type=int, default=30)
+    ap.add_argument("--tree-len", type=int, default=90)
+    ap.add_argument("--variable-lengths", action="store_true")
+    ap.add_argument("--stress", action="store_true", help="BASELINE configs[3]: hidden 1024, latent 256")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-steps", type=int, default=3)
+    return ap.parse_args()
+
+
+def cpu_baseline(a, margs_dict):
+    """the oracle (kind "port"), same model / data generator / step order, on the host cores."""
+    import copy
+    from argparse import Namespace
+    import torch
+    import oracle
+    threads = torch.get_num_threads()
+    args = Namespace(**copy.deepcopy(margs_dict))
+    src, tgt = oracle.OVocabEntry(), oracle.OVocabEntry()
+    for i in range(a.vocab - 4):
+        src.add("w%d" % i)
+    for i in range(a.tree_vocab - 4):
+        tgt.add("t%d" % i)
+    om = oracle.ORACLE_MODELS[a.model](args, oracle.OVocab(src, tgt))
+    oracle.init_uniform_(om, seed=0)
+    om.train()
+    from dss_vae_amd import synthetic
+    exs = [oracle.OExample(s, t) for s, t in synthetic.word_lists(
+        a.cpu_batch, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len, fixed=not a.variable_lengths)]
+    opt = torch.optim.Adam(om.parameters(), lr=0.0005, betas=(0.9, 0.995))
+    oracle.oracle_train_step(om, opt, exs, 6000)  # warm-up
+    ts = []
+    for i in range(a.cpu_steps):
+        t0 = time.perf_counter()
+        oracle.oracle_train_step(om, opt, exs, 6001 + i)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"value": a.cpu_batch / med, "unit": "sentences/s", "cores": threads, "kind": "port",
+            "sample": "%d timed steps (median) after 1 warm-up of the same model/config at batch %d "
+                      "(CPU oracle, torch %s, %d threads)" % (a.cpu_steps, a.cpu_batch, torch.__version__, threads),
+            "s_per_step": med}
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+    if a.gpus > 1 and world == 1:
+        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    from dss_vae_amd import ops, synthetic
+    from dss_vae_amd.models import MODEL_CLS
+    from dss_vae_amd.train import FlatAdam, build_model_params_, train_step
+    from dss_vae_amd.vae.base_vae import DeviceBatch
+
+    over = dict(synthetic.STRESS_OVERRIDES) if a.stress else {}
+    if a.model == "VanillaVAE":
+        over["tgt_wd"] = False  # the reference's tgt_wd path of VanillaVAE does not run (vanilla_vae.py:112)
+    margs = synthetic.model_args(model_select=a.model, task_type=a.model, **over)
+    margs_dict = dict(vars(margs))
+    vocab = synthetic.vocab(a.vocab, a.tree_vocab)
+    model = MODEL_CLS[a.model](args=margs, vocab=vocab)
+    build_model_params_(model, seed=0)
+    model.cuda().train()
+    n_params = sum(p.numel() for p in model.parameters())
+    opt = FlatAdam(model, lr=0.0005, betas=(0.9, 0.995), clip_grad=5.0)
+    exs = synthetic.examples(a.batch, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len,
+                             fixed=not a.variable_lengths, seed=1234 + rank)
+    batch = DeviceBatch(exs, vocab)
+    torch.manual_seed(1 + rank)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 6000
+    for _ in range(a.warmup):
+        it += 1
+        train_step(model, opt, batch, it)
+    sync()
+    timer = None if a.no_kernel_events else ops.KernelTimer()
+    ops.PROFILE = timer
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        it += 1
+        ret = train_step(model, opt, batch, it)
+    sync()
+    dt = time.perf_counter() - t0
+    ops.PROFILE = None
+    loss = float(torch.mean(ret["Loss"]).item())
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "train sentences/sec (fwd+bwd) DSS-VAE", "value": a.batch * world * a.steps / dt,
+            "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[%d]: full DSS-VAE (%s) fwd+bwd+clip+Adam, vocab %d, tree vocab %d, "
+                                   "src len %d, tree len %d%s, batch %d per GPU, E=%d H=%d Z=%d, fp32"
+                                   % (3 if a.stress else 1, a.model, a.vocab, a.tree_vocab, a.src_len, a.tree_len,
+                                      " (variable)" if a.variable_lengths else " (fixed)", a.batch, margs.embed_size,
+                                      margs.enc_hidden_dim, margs.latent_size),
+                       "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params": n_params},
+            "final_loss": loss,
+        }
+        if timer is not None:
+            summ = timer.summary()
+            kernels = []
+            for name, d in summ.items():
+                bound = KERNEL_BOUND.get(name, "hbm")
+                if bound == "mfma":
+                    ach = d["flops"] / (d["total_ms"] * 1e-3) / 1e12
+                    peak, unit = PEAK_F32_MFMA_TFLOPS, "TFLOP/s"
+                else:
+                    ach = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
+                    peak, unit = PEAK_HBM_GBS, "GB/s"
+                kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
+                                "frac": ach / peak, "traffic": None, "launches_per_step": d["launches"] / a.steps,
+                                "avg_launch_ms": d["avg_ms"], "ms_per_step": d["total_ms"] / a.steps})
+            kernels.sort(key=lambda k: -k["ms_per_step"])
+            if kernels:
+                out["roofline"] = kernels[0]
+                out["kernels"] = kernels[1:]
+                out["timed_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            del model, opt, batch
+            torch.cuda.empty_cache()
+            out["cpu_baseline"] = cpu_baseline(a, margs_dict)
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,51 @@ from . import lib as L
 _CUS = None
 
 
+class KernelTimer(object):
+    """HIP-event spans around single launches on the stream they are launched on (torch's current
+    stream).  bench.py installs one as ``ops.PROFILE`` for its timed region to get each kernel's
+    average launch duration live; with ``PROFILE = None`` (default) nothing is recorded."""
+
+    def __init__(self):
+        self.spans = []  # (kernel name, start event, end event, algorithmic flops, algorithmic bytes)
+
+    def summary(self):
+        """-> {kernel: dict(launches, total_ms, avg_ms, flops, bytes)}; call after a device sync."""
+        out = {}
+        for name, e0, e1, fl, by in self.spans:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+            d["launches"] += 1
+            d["total_ms"] += e0.elapsed_time(e1)
+            d["flops"] += fl
+            d["bytes"] += by
+        for d in out.values():
+            d["avg_ms"] = d["total_ms"] / d["launches"]
+        return out
+
+
+PROFILE = None
+
+
+class _Span(object):
+    __slots__ = ("name", "flops", "bytes", "e0")
+
+    def __init__(self, name, flops, nbytes):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes)))
+        return False
+
+
 def n_cus():
     global _CUS
     if _CUS is None:
@@ -36,8 +81,9 @@ def _rows(t):
 # ----------------------------------------------------------------------------------------------
 def _gemm(A, lda, ta, B, ldb, tb, Cm, ldc, bias, M, N, K, alpha=1.0, beta=0.0, a_rows=None):
     L.require_cuda(A, B, Cm)
-    L.check(L.load().dssvae_gemm_f32(L.ptr(A), lda, int(ta), L.ptr(a_rows), L.ptr(B), ldb, int(tb), L.ptr(Cm), ldc,
-                                     L.ptr(bias), M, N, K, alpha, beta, L.stream()), "dssvae_gemm_f32")
+    with _Span("gemm_store_kernel", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+        L.check(L.load().dssvae_gemm_f32(L.ptr(A), lda, int(ta), L.ptr(a_rows), L.ptr(B), ldb, int(tb), L.ptr(Cm),
+                                         ldc, L.ptr(bias), M, N, K, alpha, beta, L.stream()), "dssvae_gemm_f32")
 
 
 def mm_nt(x, w, bias=None, out=None, beta=0.0):
@@ -228,9 +274,10 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False):
     ps = torch.empty(M, S, device=dev, dtype=torch.float32)
     pa = torch.empty(M, S, device=dev, dtype=torch.int64) if want_arg else None
     lib = L.load()
-    L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
-                                      L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.stream()),
-            "dssvae_linear_lse_fwd")
+    with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S)):
+        L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
+                                          L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.stream()),
+                "dssvae_linear_lse_fwd")
     lse = torch.empty(M, device=dev, dtype=torch.float32)
     arg = torch.empty(M, device=dev, dtype=torch.int64) if want_arg else None
     L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, L.ptr(lse), L.ptr(arg), L.stream()),
@@ -301,9 +348,11 @@ class _LinearCEFn(Function):
             xh_c = xh[m0:m0 + mc]
             xe_c = xe[m0:m0 + mc] if xe is not None else None
             dl = slab[:mc]
-            L.check(lib.dssvae_linear_ce_dlogits(L.ptr(xh_c), ldh, Kh, L.ptr(xe_c), lde, Ke, L.ptr(W), ldw, L.ptr(b),
-                                                 L.ptr(lse[m0:]), L.ptr(coef[m0:]), mc, N, L.ptr(dl), ldd,
-                                                 L.stream()), "dssvae_linear_ce_dlogits")
+            with _Span("linear_dlogits_kernel", 2.0 * mc * N * (Kh + Ke),
+                       4.0 * (mc * (Kh + Ke) + N * (Kh + Ke) + mc * N)):
+                L.check(lib.dssvae_linear_ce_dlogits(L.ptr(xh_c), ldh, Kh, L.ptr(xe_c), lde, Ke, L.ptr(W), ldw,
+                                                     L.ptr(b), L.ptr(lse[m0:]), L.ptr(coef[m0:]), mc, N, L.ptr(dl),
+                                                     ldd, L.stream()), "dssvae_linear_ce_dlogits")
             L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(g_mt[m0:]), mc, N,
                                           L.stream()), "dssvae_onehot_sub")
             dlv = dl[:, :N]
@@ -415,7 +464,10 @@ class _GruFn(Function):
                     None if gates[i] is None else gates[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
                     int(meta["reverse"][i]))
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
-            L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
+            fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
+            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save else 4) for i in launch)
+            with _Span("gru_fwd_kernel", fl, by):
+                L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
@@ -451,7 +503,10 @@ class _GruFn(Function):
                     dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
                     int(meta["reverse"][i]))
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
-            L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
+            fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
+            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
+            with _Span("gru_bwd_kernel", fl, by):
+                L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         out = [None]
@@ -507,5 +562,6 @@ def sumsq(flat, out):
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm):
-    L.check(L.load().dssvae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps, step,
-                                      L.ptr(sumsq_t), max_norm, None, L.stream()), "dssvae_adam_step")
+    with _Span("adam_kernel", 0.0, 28.0 * p.numel()):
+        L.check(L.load().dssvae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps,
+                                          step, L.ptr(sumsq_t), max_norm, None, L.stream()), "dssvae_adam_step")
