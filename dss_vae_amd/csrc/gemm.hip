@@ -1,224 +1,295 @@
-// fp32 MFMA GEMM family for gfx950: one LDS-tiled mainloop (128x128x32 block, 4 waves, each
-// wave a 2x2 grid of v_mfma_f32_32x32x2_f32 tiles), four epilogues:
-//   STORE    C = alpha*A.B^T + beta*C + bias                      (x-projections, dgrad, wgrad)
-//   LSE      online log-sum-exp over column splits, no logits out  (fused vocab projection + CE)
-//   DLOGITS  coef[m]*exp(logit - lse[m]) into a row-chunk slab     (CE backward recompute)
-// Roofline: fp32 MFMA (157 TFLOP/s dense).  LDS image is k-major ([k][m]) because the f32 MFMA
-// operand map is lane -> (row = lane&31, k = lane>>5): a fragment read is 32 consecutive floats.
+// fp32 MFMA GEMM family for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 157 TFLOP/s dense peak).
+//
+// One LDS-tiled mainloop, (64*WM) x (64*WN) x 32 block, 4 waves as 2x2, each wave a WM x WN grid of
+// 32x32 MFMA tiles, double-buffered LDS with register staging (loads of k-tile t+1 are in flight
+// while tile t is multiplied; one barrier per k-tile).  Three epilogues:
+//   STORE    C = alpha*A.B^T + beta*C + bias, optional split-K (atomic accumulate)
+//   LSE      online log-sum-exp (+argmax) over column splits, logits never written
+//   DLOGITS  coef[m]*exp(logit - lse[m]) into a slab, + column sums for the bias gradient
+//
+// Operand images in LDS.  The f32 MFMA takes ONE float per lane per operand: lane l supplies
+// A[row l&31][k-slot l>>5].  Which k a (step, lane-half) pair multiplies is free as long as A and
+// B agree; here k(g, j, h) = 8g + 4h + j  (g: group of 8 k, j: MFMA within the group, h = l>>5).
+//   * k-contiguous operand (row-major [rows, K]: activations, nn.Linear weights): image
+//     [rows][36]; global float4 -> ds_write_b128 as is (no transposing stores), and a lane's four
+//     j-values of a group are ONE ds_read_b128 (row stride 36 floats: conflict-free for every
+//     16-lane ds_read_b128 group).
+//   * row-contiguous operand (memory [K, rows]: the transposed operands of dgrad / wgrad): image
+//     [32][rows+4]; float4 along rows in, ds_read_b32 out (32 consecutive floats per lane-half).
+// The fast path (VEC) has no branches in the mainloop: out-of-range rows read a clamped valid
+// row (their results are never stored), the k tail is zeroed by select.  Shapes whose leading
+// dimensions / K are not multiples of 4 floats take the scalar-load instantiation (same math).
 #include "common.h"
+#include <hip/amd_detail/amd_hip_unsafe_atomics.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 32, NTHREADS = 256;
-constexpr int LD_KC = 129;  // operand stored k-contiguous in memory: transposing ds_write_b32, conflict-free
-constexpr int LD_RC = 132;  // operand stored row-contiguous in memory: ds_write_b128, 16-B aligned rows
+constexpr int BK = 32, NTHREADS = 256;
+constexpr int LDK = BK + 4;
 constexpr float NEG_BIG = -3.0e38f;
 
 struct OpA {
     const float* p1; int64_t ld1; int K1;
     const float* p2; int64_t ld2;
     const int64_t* rows;
-    int vec;
 };
 struct OpB {
-    const float* p; int64_t ld; int vec;
+    const float* p; int64_t ld;
 };
 
-template <bool T> struct LdsLd { static constexpr int v = T ? LD_RC : LD_KC; };
+constexpr int img_floats(bool trans, int R) { return trans ? BK * (R + 4) : R * LDK; }
+template <bool TA, bool TB, int WM, int WN>
+constexpr int lds_floats() { return 2 * (img_floats(TA, 64 * WM) + img_floats(TB, 64 * WN)); }
 
-// ---- global -> register staging --------------------------------------------------------------
-// k-contiguous operand: thread t covers rows (t>>3)+32*i, i=0..3, at k = k0 + 4*(t&7)
-struct RowBase {
-    const float* b1[4];
-    const float* b2[4];
-    bool ok[4];
-};
+// ---- global -> register -> LDS staging of one operand tile (R rows x 32 k) -----------------------
+template <bool TRANS, bool VEC, int R>
+struct Stager {
+    static constexpr int NV = R / 32;   // float4 per thread (VEC)
+    static constexpr int NS = R / 8;    // floats per thread (scalar)
+    float4 v[VEC ? NV : 1];
+    float s[VEC ? 1 : NS];
+    const float* b1[(!TRANS && VEC) ? NV : 1];
+    const float* b2[(!TRANS && VEC) ? NV : 1];
+    const float* p1; const float* p2; const int64_t* rows;
+    int64_t ld1, ld2;
+    int K1, K, Rtot, r0;
 
-__device__ __forceinline__ void stage_kc(float4 (&reg)[4], const RowBase& rb, int K1, int K, int k0, int vec) {
-    const int k = k0 + 4 * (threadIdx.x & 7);
+    __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int K1_, const float* p2_, int64_t ld2_,
+                                         const int64_t* rows_, int Rtot_, int r0_, int K_) {
+        p1 = p1_; ld1 = ld1_; K1 = K1_; p2 = p2_ ? p2_ : p1_; ld2 = p2_ ? ld2_ : ld1_; rows = rows_;
+        Rtot = Rtot_; r0 = r0_; K = K_;
+        if (!TRANS && VEC) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (rb.ok[i]) {
-            if (vec) {
-                if (k < K) v = *reinterpret_cast<const float4*>(k < K1 ? rb.b1[i] + k : rb.b2[i] + (k - K1));
-            } else {
-                float e[4];
+            for (int i = 0; i < NV; ++i) {
+                const int r = min(r0 + (int)(threadIdx.x >> 3) + 32 * i, Rtot - 1);
+                const int64_t ri = rows ? rows[r] : (int64_t)r;
+                b1[i] = p1 + ri * ld1;
+                b2[i] = p2 + ri * ld2;
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load(int k0) {
+        if (!TRANS) {
+            if (VEC) {
+                const int k = k0 + 4 * (threadIdx.x & 7);
+                const bool ok = k < K;
+                const int kc = ok ? k : 0;
+                const bool first = kc < K1;
+                const int off = first ? kc : kc - K1;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int kk = k + j;
-                    e[j] = kk < K ? (kk < K1 ? rb.b1[i][kk] : rb.b2[i][kk - K1]) : 0.f;
+                for (int i = 0; i < NV; ++i) {
+                    const float* src = (first ? b1[i] : b2[i]) + off;
+                    float4 t = *reinterpret_cast<const float4*>(src);
+                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[i] = t;
                 }
-                v = make_float4(e[0], e[1], e[2], e[3]);
-            }
-        }
-        reg[i] = v;
-    }
-}
-
-__device__ __forceinline__ void store_kc(float* lds, const float4 (&reg)[4]) {
-    const int kq = 4 * (threadIdx.x & 7), r = threadIdx.x >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float* d = lds + kq * LD_KC + r + 32 * i;
-        d[0] = reg[i].x; d[LD_KC] = reg[i].y; d[2 * LD_KC] = reg[i].z; d[3 * LD_KC] = reg[i].w;
-    }
-}
-
-// row-contiguous operand (memory is [k][rows]): thread t covers k = k0 + (t>>5) + 8*i at rows 4*(t&31)..+3
-__device__ __forceinline__ void stage_rc(float4 (&reg)[4], const float* p, int64_t ld, int R, int row0, int K,
-                                         int k0, int vec) {
-    const int r4 = row0 + 4 * (threadIdx.x & 31);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int k = k0 + (threadIdx.x >> 5) + 8 * i;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < K) {
-            const float* s = p + (int64_t)k * ld + r4;
-            if (vec && r4 + 3 < R) {
-                v = *reinterpret_cast<const float4*>(s);
             } else {
-                if (r4 < R) v.x = s[0];
-                if (r4 + 1 < R) v.y = s[1];
-                if (r4 + 2 < R) v.z = s[2];
-                if (r4 + 3 < R) v.w = s[3];
+                const int k = k0 + (threadIdx.x & 31);
+                const bool ok = k < K;
+                const int kc = ok ? k : 0;
+                const bool first = kc < K1;
+                const int off = first ? kc : kc - K1;
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const int r = min(r0 + (int)(threadIdx.x >> 5) + 8 * e, Rtot - 1);
+                    const int64_t ri = rows ? rows[r] : (int64_t)r;
+                    const float t = first ? p1[ri * ld1 + off] : p2[ri * ld2 + off];
+                    s[e] = ok ? t : 0.f;
+                }
+            }
+        } else {
+            if (VEC) {
+                constexpr int TPK = R / 4;          // threads per k row
+                constexpr int KSTEP = NTHREADS / TPK;
+                const int r4 = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int k = k0 + (int)(threadIdx.x / TPK) + KSTEP * i;
+                    const bool ok = k < K;
+                    float4 t = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
+                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[i] = t;
+                }
+            } else {
+                constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
+                const int r = min(r0 + (int)(threadIdx.x % R), Rtot - 1);
+#pragma unroll
+                for (int e = 0; e < NS; ++e) {
+                    const int k = k0 + (int)(threadIdx.x / R) + KSTEP * e;
+                    const bool ok = k < K;
+                    const float t = p1[(int64_t)(ok ? k : 0) * ld1 + r];
+                    s[e] = ok ? t : 0.f;
+                }
             }
         }
-        reg[i] = v;
+    }
+
+    __device__ __forceinline__ void store(float* img) const {
+        if (!TRANS) {
+            if (VEC) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    *reinterpret_cast<float4*>(img + ((threadIdx.x >> 3) + 32 * i) * LDK + 4 * (threadIdx.x & 7)) = v[i];
+            } else {
+#pragma unroll
+                for (int e = 0; e < NS; ++e) img[((threadIdx.x >> 5) + 8 * e) * LDK + (threadIdx.x & 31)] = s[e];
+            }
+        } else {
+            if (VEC) {
+                constexpr int TPK = R / 4;
+                constexpr int KSTEP = NTHREADS / TPK;
+#pragma unroll
+                for (int i = 0; i < NV; ++i)
+                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) = v[i];
+            } else {
+                constexpr int KSTEP = NTHREADS / R;
+#pragma unroll
+                for (int e = 0; e < NS; ++e) img[((threadIdx.x / R) + KSTEP * e) * (R + 4) + (threadIdx.x % R)] = s[e];
+            }
+        }
+    }
+};
+
+// fragment of one 32-row MFMA tile for group g: f[j] multiplies k = 8g + 4h + j
+template <bool TRANS, int R>
+__device__ __forceinline__ void read_frag(float (&f)[4], const float* img, int row, int g, int h) {
+    if (!TRANS) {
+        const float4 t = *reinterpret_cast<const float4*>(img + row * LDK + 8 * g + 4 * h);
+        f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+    } else {
+        const float* p = img + (8 * g + 4 * h) * (R + 4) + row;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) f[j] = p[j * (R + 4)];
     }
 }
 
-__device__ __forceinline__ void store_rc(float* lds, const float4 (&reg)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-        *reinterpret_cast<float4*>(lds + ((threadIdx.x >> 5) + 8 * i) * LD_RC + 4 * (threadIdx.x & 31)) = reg[i];
-}
-
-// ---- one 128x128 output tile, full K --------------------------------------------------------
-template <bool TA, bool TB>
+// ---- one (64*WM) x (64*WN) output tile over k-tiles [kt0, kt1) -----------------------------------
+template <bool TA, bool TB, bool VEC, int WM, int WN>
 __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M, int N, int K, int m0, int n0,
-                                              float* lds, f32x16 (&acc)[2][2]) {
-    constexpr int LDA = LdsLd<TA>::v, LDB = LdsLd<TB>::v;
-    float* As = lds;                       // [2][BK*LDA]
-    float* Bs = lds + 2 * BK * LDA;        // [2][BK*LDB]
+                                              int kt0, int kt1, float* lds, f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AF = img_floats(TA, BM), BF = img_floats(TB, BN);
+    float* As = lds;            // [2][AF]
+    float* Bs = lds + 2 * AF;   // [2][BF]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave >> 1, wc = wave & 1, h = lane >> 5;
+    const int arow = wr * 32 * WM + (lane & 31), brow = wc * 32 * WN + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    RowBase ra, rbB;
-    if (!TA) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = m0 + (threadIdx.x >> 3) + 32 * i;
-            ra.ok[i] = gr < M;
-            const int64_t ri = ra.ok[i] ? (a.rows ? a.rows[gr] : (int64_t)gr) : 0;
-            ra.b1[i] = a.p1 + ri * a.ld1;
-            ra.b2[i] = a.p2 ? a.p2 + ri * a.ld2 : a.p1;
-        }
-    }
-    if (!TB) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gr = n0 + (threadIdx.x >> 3) + 32 * i;
-            rbB.ok[i] = gr < N;
-            rbB.b1[i] = b.p + (int64_t)(rbB.ok[i] ? gr : 0) * b.ld;
-            rbB.b2[i] = rbB.b1[i];
-        }
-    }
-    float4 rA[4], rB[4];
-    const int nk = (K + BK - 1) / BK;
-    auto stage = [&](int kt) {
-        if (TA) stage_rc(rA, a.p1, a.ld1, M, m0, K, kt * BK, a.vec);
-        else stage_kc(rA, ra, a.K1, K, kt * BK, a.vec);
-        if (TB) stage_rc(rB, b.p, b.ld, N, n0, K, kt * BK, b.vec);
-        else stage_kc(rB, rbB, K, K, kt * BK, b.vec);
-    };
-    auto commit = [&](int buf) {
-        if (TA) store_rc(As + buf * BK * LDA, rA); else store_kc(As + buf * BK * LDA, rA);
-        if (TB) store_rc(Bs + buf * BK * LDB, rB); else store_kc(Bs + buf * BK * LDB, rB);
-    };
-    stage(0);
-    commit(0);
+    Stager<TA, VEC, BM> sa;
+    Stager<TB, VEC, BN> sb;
+    sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K);
+    sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
+
+    sa.load(kt0 * BK);
+    sb.load(kt0 * BK);
+    sa.store(As);
+    sb.store(Bs);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1);
-        const float* Ab = As + cur * BK * LDA + wr * 64 + (lane & 31);
-        const float* Bb = Bs + cur * BK * LDB + wc * 64 + (lane & 31);
-#pragma unroll
-        for (int ks = 0; ks < BK / 2; ++ks) {
-            const int kidx = 2 * ks + (lane >> 5);
-            const float a0 = Ab[kidx * LDA], a1 = Ab[kidx * LDA + 32];
-            const float b0 = Bb[kidx * LDB], b1 = Bb[kidx * LDB + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) {
+            sa.load((kt + 1) * BK);
+            sb.load((kt + 1) * BK);
         }
-        if (kt + 1 < nk) commit(cur ^ 1);
+        const float* Ab = As + cur * AF;
+        const float* Bb = Bs + cur * BF;
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float fa[WM][4], fb[WN][4];
+#pragma unroll
+            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[i], Ab, arow + 32 * i, g, h);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[j], Bb, brow + 32 * j, g, h);
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                for (int i = 0; i < WM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][jj], fb[j][jj], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            sa.store(As + (cur ^ 1) * AF);
+            sb.store(Bs + (cur ^ 1) * BF);
+        }
         __syncthreads();
     }
 }
 
-constexpr int lds_floats(bool ta, bool tb) { return 2 * BK * ((ta ? LD_RC : LD_KC) + (tb ? LD_RC : LD_KC)); }
-
 // accumulator element (mt, nt, r) of this lane -> tile-local (row, col)
+template <int WM>
 __device__ __forceinline__ int acc_row(int mt, int r) {
     const int lane = threadIdx.x & 63, wr = threadIdx.x >> 7;
-    return wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    return wr * 32 * WM + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 }
+template <int WN>
 __device__ __forceinline__ int acc_col(int nt) {
     const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) & 1;
-    return wc * 64 + nt * 32 + (lane & 31);
+    return wc * 32 * WN + nt * 32 + (lane & 31);
 }
 
-// ---- STORE ------------------------------------------------------------------------------------
-template <bool TA, bool TB>
+// ---- STORE ---------------------------------------------------------------------------------------
+template <bool TA, bool TB, bool VEC, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
                                                                const float* __restrict__ bias, int M, int N, int K,
-                                                               float alpha, float beta, int tiles_n, int ntiles) {
+                                                               float alpha, float beta, int tiles_n, int ntiles,
+                                                               int ksplit, int kt_per_split) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
+    const int tile = wid / ksplit, ks = wid - tile * ksplit;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    f32x16 acc[2][2];
-    tile_mainloop<TA, TB>(a, b, M, N, K, m0, n0, lds, acc);
+    const int nk = (K + BK - 1) / BK;
+    const int kt0 = ks * kt_per_split, kt1 = min(nk, kt0 + kt_per_split);
+    if (kt0 >= kt1) return;
+    f32x16 acc[WM][WN];
+    tile_mainloop<TA, TB, VEC, WM, WN>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        const int n = n0 + acc_col(nt);
+    for (int nt = 0; nt < WN; ++nt) {
+        const int n = n0 + acc_col<WN>(nt);
         if (n >= N) continue;
-        const float bv = bias ? bias[n] : 0.f;
+        const float bv = (bias && ks == 0) ? bias[n] : 0.f;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + acc_row(mt, r);
+                const int m = m0 + acc_row<WM>(mt, r);
                 if (m < M) {
                     float v = alpha * acc[mt][nt][r] + bv;
                     float* c = C + (int64_t)m * ldc + n;
-                    if (beta != 0.f) v += beta * *c;
-                    *c = v;
+                    if (ksplit > 1) {
+                        unsafeAtomicAdd(c, v);  // C was zeroed (beta = 0) or holds the addend (beta = 1)
+                    } else {
+                        if (beta != 0.f) v += beta * *c;
+                        *c = v;
+                    }
                 }
             }
     }
 }
 
-// ---- LSE (optionally with argmax) ------------------------------------------------------------
-template <bool ARG>
+// ---- LSE (optionally with argmax) ----------------------------------------------------------------
+template <bool ARG, bool VEC>
 __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
                                                                int N, int K, int n_split, int tiles_per_split,
                                                                int tiles_n, float* __restrict__ part_max,
                                                                float* __restrict__ part_sum,
                                                                int64_t* __restrict__ part_arg) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = 128, BN = 128;
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
     const int m0 = mb * BM;
     const int t_begin = split * tiles_per_split;
     const int t_end = min(t_begin + tiles_per_split, tiles_n);
+    const int nk = (K + BK - 1) / BK;
     float rm[2][16], rs[2][16];
     int ra[2][16];
 #pragma unroll
@@ -229,25 +300,25 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x16 acc[2][2];
-        tile_mainloop<false, false>(a, b, M, N, K, m0, n0, lds, acc);
+        tile_mainloop<false, false, VEC, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
+        const int c0 = n0 + acc_col<2>(0), c1 = n0 + acc_col<2>(1);
+        const bool ok0 = c0 < N, ok1 = c1 < N;
+        const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int n = n0 + acc_col(nt);
-            if (n < N) {
-                const float bv = bias ? bias[n] : 0.f;
+        for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float x = acc[mt][nt][r] + bv;
-                        const float mo = rm[mt][r];
-                        const float mn = fmaxf(mo, x);
-                        rs[mt][r] = rs[mt][r] * __expf(mo - mn) + __expf(x - mn);
-                        if (ARG) { if (x > mo) ra[mt][r] = n; }
-                        rm[mt][r] = mn;
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const float x0 = ok0 ? acc[mt][0][r] + b0 : NEG_BIG;
+                const float x1 = ok1 ? acc[mt][1][r] + b1 : NEG_BIG;
+                const float mo = rm[mt][r];
+                const float mn = fmaxf(mo, fmaxf(x0, x1));
+                rs[mt][r] = rs[mt][r] * __expf(mo - mn) + __expf(x0 - mn) + __expf(x1 - mn);
+                if (ARG) {
+                    if (x0 > mo && x0 >= x1) ra[mt][r] = c0;
+                    else if (x1 > mo) ra[mt][r] = c1;
+                }
+                rm[mt][r] = mn;
             }
-        }
     }
     // reduce over the 32 lanes that hold different columns of the same rows
 #pragma unroll
@@ -275,7 +346,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float* d = red + (wc * BM + acc_row(mt, r)) * 3;
+                float* d = red + (wc * BM + acc_row<2>(mt, r)) * 3;
                 d[0] = rm[mt][r]; d[1] = rs[mt][r]; d[2] = __int_as_float(ra[mt][r]);
             }
     }
@@ -314,30 +385,42 @@ __global__ void lse_combine_kernel(const float* __restrict__ pm, const float* __
     if (amax && pa) amax[m] = pa[(int64_t)m * S + best];
 }
 
-// ---- DLOGITS ---------------------------------------------------------------------------------
+// ---- DLOGITS -------------------------------------------------------------------------------------
+template <bool VEC>
 __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, const float* __restrict__ bias,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ coef, int M, int N, int K,
-                                                                   float* __restrict__ dL, int64_t ldd, int tiles_n,
-                                                                   int ntiles) {
+                                                                   float* __restrict__ dL, int64_t ldd,
+                                                                   float* __restrict__ colsum, int tiles_n, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = 128, BN = 128;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     f32x16 acc[2][2];
-    tile_mainloop<false, false>(a, b, M, N, K, m0, n0, lds, acc);
+    tile_mainloop<false, false, VEC, 2, 2>(a, b, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
+    const int c0 = n0 + acc_col<2>(0), c1 = n0 + acc_col<2>(1);
+    const bool ok0 = c0 < N, ok1 = c1 < N;
+    const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
+    float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + acc_row(mt, r);
+            const int m = m0 + acc_row<2>(mt, r);
             if (m >= M) continue;
             const float l = lse[m], c = coef[m];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt) {
-                const int n = n0 + acc_col(nt);
-                if (n < N) dL[(int64_t)m * ldd + n] = c * __expf(acc[mt][nt][r] + (bias ? bias[n] : 0.f) - l);
-            }
+            float* row = dL + (int64_t)m * ldd;
+            if (ok0) { const float v = c * __expf(acc[mt][0][r] + b0 - l); row[c0] = v; s0 += v; }
+            if (ok1) { const float v = c * __expf(acc[mt][1][r] + b1 - l); row[c1] = v; s1 += v; }
         }
+    if (colsum) {
+        s0 += __shfl_xor(s0, 32, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        if ((threadIdx.x & 63) < 32) {
+            if (ok0) unsafeAtomicAdd(colsum + c0, s0);
+            if (ok1) unsafeAtomicAdd(colsum + c1, s1);
+        }
+    }
 }
 
 // picked[m,t] = X[m,:] . W[target,:] + bias[target]; one wave per (m,t)
@@ -363,29 +446,30 @@ __global__ void picked_logit_kernel(const float* __restrict__ Xh, int64_t ldh, i
 }
 
 __global__ void onehot_sub_kernel(float* __restrict__ dL, int64_t ldd, const int64_t* __restrict__ target,
-                                  int64_t ignore, const float* __restrict__ g, int64_t total, int T, int N) {
+                                  int64_t ignore, const float* __restrict__ g, int64_t total, int T, int64_t n0,
+                                  int64_t n1, float* __restrict__ colsum) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int64_t tg = target[idx];
-    if (tg == ignore || tg < 0 || tg >= N) return;
-    atomicAdd(dL + (idx / T) * ldd + tg, -g[idx]);
+    if (tg == ignore || tg < n0 || tg >= n1) return;
+    const float gv = g[idx];
+    unsafeAtomicAdd(dL + (idx / T) * ldd + (tg - n0), -gv);
+    if (colsum) unsafeAtomicAdd(colsum + (tg - n0), -gv);
 }
 
-// out[n] (+)= sum_m X[m,n]; block = 64 columns x 4 row slices
+// out[n] (+)= sum_m X[m,n]; block = 64 columns x 4 row slices, grid.y row chunks (atomic combine)
 __global__ void colsum_kernel(const float* __restrict__ X, int64_t ldx, int M, int N, float* __restrict__ out,
-                              int accumulate) {
+                              int rows_per_block) {
     __shared__ float red[4][64];
     const int c = threadIdx.x & 63, rs = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
     float s = 0.f;
     if (n < N)
-        for (int m = rs; m < M; m += 4) s += X[(int64_t)m * ldx + n];
+        for (int m = m_begin + rs; m < m_end; m += 4) s += X[(int64_t)m * ldx + n];
     red[rs][c] = s;
     __syncthreads();
-    if (rs == 0 && n < N) {
-        const float v = red[0][c] + red[1][c] + red[2][c] + red[3][c];
-        out[n] = accumulate ? out[n] + v : v;
-    }
+    if (rs == 0 && n < N) unsafeAtomicAdd(out + n, red[0][c] + red[1][c] + red[2][c] + red[3][c]);
 }
 
 template <typename F>
@@ -396,11 +480,60 @@ void allow_lds(F* func, int bytes) {
 
 bool vec_ok(const float* p, int64_t ld) { return p == nullptr || (aligned16(p) && (ld % 4) == 0); }
 
-OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke) {
+OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, bool* vec) {
     OpA a;
     a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr;
-    a.vec = vec_ok(Xh, ldh) && (Ke == 0 || vec_ok(Xe, lde)) && (Kh % 4 == 0) && (Ke % 4 == 0);
+    *vec = vec_ok(Xh, ldh) && (Ke == 0 || vec_ok(Xe, lde)) && (Kh % 4 == 0) && (Ke % 4 == 0);
     return a;
+}
+
+int n_cus_cached() {
+    static int cus = 0;
+    if (cus == 0) {
+        int n = 0;
+        if (dssvae_device_cus(&n) != 0 || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+template <bool TA, bool TB, bool VEC, int WM, int WN>
+int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
+                 float alpha, float beta, int ksplit_req, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    const int nk = (K + BK - 1) / BK;
+    int ksplit = ksplit_req;
+    if (ksplit <= 0) {  // auto: fill ~2 workgroups per CU, keep >= 8 k-tiles per split
+        const int slots = 2 * n_cus_cached();
+        ksplit = 1;
+        if (ntiles * 2 <= slots) ksplit = min(slots / ntiles, max(1, nk / 8));
+    }
+    if (beta != 0.f && beta != 1.f) ksplit = 1;
+    ksplit = max(1, min(ksplit, nk));
+    int ktps = (nk + ksplit - 1) / ksplit;
+    ksplit = (nk + ktps - 1) / ktps;  // no empty splits
+    if (ksplit > 1 && beta == 0.f) {
+        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
+    auto kern = gemm_store_kernel<TA, TB, VEC, WM, WN>;
+    allow_lds(kern, lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(ntiles * ksplit), dim3(NTHREADS), lds_bytes, s, a, b, C, ldc, bias, M, N, K, alpha,
+                       beta, tiles_n, ntiles, ksplit, ktps);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+template <bool TA, bool TB, bool VEC>
+int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
+                      float alpha, float beta, int ksplit, hipStream_t s) {
+    // 128x64 tiles when they waste fewer columns than 128x128 or when 128x128 would under-fill the chip
+    const int t128 = (N + 127) / 128, t64 = (N + 63) / 64;
+    const bool narrow = (t64 * 64 < t128 * 128) || ((int64_t)((M + 127) / 128) * t128 < n_cus_cached());
+    if (narrow) return launch_store<TA, TB, VEC, 2, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
+    return launch_store<TA, TB, VEC, 2, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
 }
 
 }  // namespace
@@ -408,28 +541,33 @@ OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t l
 extern "C" int dssvae_gemm_f32(const float* A, int64_t lda, int trans_a, const int64_t* a_rows, const float* B,
                                int64_t ldb, int trans_b, float* C, int64_t ldc, const float* bias, int M, int N,
                                int K, float alpha, float beta, void* stream) {
-    if (!A || !B || !C || M < 0 || N < 0 || K <= 0) return DSSVAE_EINVAL;
+    return dssvae_gemm_f32_splitk(A, lda, trans_a, a_rows, B, ldb, trans_b, C, ldc, bias, M, N, K, alpha, beta, 0,
+                                  stream);
+}
+
+extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64_t* a_rows,
+                                      const float* B, int64_t ldb, int trans_b, float* C, int64_t ldc,
+                                      const float* bias, int M, int N, int K, float alpha, float beta, int ksplit,
+                                      void* stream) {
+    if (!A || !B || !C || M < 0 || N < 0 || K <= 0 || ldc < N) return DSSVAE_EINVAL;
     if (trans_a && a_rows) return DSSVAE_EINVAL;
+    if ((trans_a ? lda < M : lda < K) || (trans_b ? ldb < N : ldb < K)) return DSSVAE_EINVAL;
     if (M == 0 || N == 0) return DSSVAE_OK;
     OpA a;
     a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows;
-    a.vec = vec_ok(A, lda) && (trans_a ? true : (K % 4 == 0));
     OpB b;
     b.p = B; b.ld = ldb;
-    b.vec = vec_ok(B, ldb) && (trans_b ? true : (K % 4 == 0));
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
+    // fast path: every float4 granule of both operands is aligned and entirely in or out of range
+    const bool va = vec_ok(A, lda) && (trans_a ? (M % 4 == 0 && M >= 4) : (K % 4 == 0));
+    const bool vb = vec_ok(B, ldb) && (trans_b ? (N % 4 == 0 && N >= 4) : (K % 4 == 0));
+    const bool vec = va && vb;
     hipStream_t s = (hipStream_t)stream;
-#define LAUNCH(TA, TB)                                                                                            \
-    do {                                                                                                          \
-        allow_lds(gemm_store_kernel<TA, TB>, lds_floats(TA, TB) * 4);                                             \
-        hipLaunchKernelGGL((gemm_store_kernel<TA, TB>), dim3(ntiles), dim3(NTHREADS), lds_floats(TA, TB) * 4, s, \
-                           a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ntiles);                            \
-    } while (0)
-    if (trans_a) { if (trans_b) LAUNCH(true, true); else LAUNCH(true, false); }
-    else { if (trans_b) LAUNCH(false, true); else LAUNCH(false, false); }
-#undef LAUNCH
-    DSSVAE_CHECK_LAUNCH();
-    return DSSVAE_OK;
+#define GO(TA, TB)                                                                                              \
+    return vec ? launch_store_tile<TA, TB, true>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)          \
+               : launch_store_tile<TA, TB, false>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)
+    if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
+    else { if (trans_b) GO(false, true); else GO(false, false); }
+#undef GO
 }
 
 extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
@@ -440,22 +578,25 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
         return DSSVAE_EINVAL;
     if (Ke > 0 && !Xe) return DSSVAE_EINVAL;
     if (want_argmax && !part_arg) return DSSVAE_EINVAL;
-    OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke);
+    bool vec;
+    OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke, &vec);
     OpB b;
-    b.p = W; b.ld = ldw; b.vec = vec_ok(W, ldw) && ((Kh + Ke) % 4 == 0);
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    b.p = W; b.ld = ldw;
+    vec = vec && vec_ok(W, ldw);
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    if (n_split > tiles_n) return DSSVAE_EINVAL;
     const int tps = (tiles_n + n_split - 1) / n_split;
     hipStream_t s = (hipStream_t)stream;
-    allow_lds(linear_lse_kernel<true>, lds_floats(false, false) * 4);
-    allow_lds(linear_lse_kernel<false>, lds_floats(false, false) * 4);
-    if (want_argmax)
-        hipLaunchKernelGGL((linear_lse_kernel<true>), dim3(tiles_m * n_split), dim3(NTHREADS),
-                           lds_floats(false, false) * 4, s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n,
-                           part_max, part_sum, part_arg);
-    else
-        hipLaunchKernelGGL((linear_lse_kernel<false>), dim3(tiles_m * n_split), dim3(NTHREADS),
-                           lds_floats(false, false) * 4, s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n,
-                           part_max, part_sum, part_arg);
+    constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
+#define GO(ARG, VEC)                                                                                             \
+    do {                                                                                                         \
+        allow_lds(linear_lse_kernel<ARG, VEC>, lds_bytes);                                                       \
+        hipLaunchKernelGGL((linear_lse_kernel<ARG, VEC>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes, s, \
+                           a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg);      \
+    } while (0)
+    if (want_argmax) { if (vec) GO(true, true); else GO(true, false); }
+    else { if (vec) GO(false, true); else GO(false, false); }
+#undef GO
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -482,34 +623,52 @@ extern "C" int dssvae_picked_logit(const float* Xh, int64_t ldh, int Kh, const f
 
 extern "C" int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
                                         const float* W, int64_t ldw, const float* bias, const float* lse,
-                                        const float* coef, int M, int N, float* dL, int64_t ldd, void* stream) {
+                                        const float* coef, int M, int N, float* dL, int64_t ldd, float* colsum,
+                                        void* stream) {
     if (!Xh || !W || !lse || !coef || !dL || M <= 0 || N <= 0 || Kh <= 0 || ldd < N || (Ke > 0 && !Xe))
         return DSSVAE_EINVAL;
-    OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke);
+    bool vec;
+    OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke, &vec);
     OpB b;
-    b.p = W; b.ld = ldw; b.vec = vec_ok(W, ldw) && ((Kh + Ke) % 4 == 0);
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
-    allow_lds(linear_dlogits_kernel, lds_floats(false, false) * 4);
-    hipLaunchKernelGGL(linear_dlogits_kernel, dim3(ntiles), dim3(NTHREADS), lds_floats(false, false) * 4,
-                       (hipStream_t)stream, a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, tiles_n, ntiles);
+    b.p = W; b.ld = ldw;
+    vec = vec && vec_ok(W, ldw);
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, ntiles = tiles_m * tiles_n;
+    constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
+    if (vec) {
+        allow_lds(linear_dlogits_kernel<true>, lds_bytes);
+        hipLaunchKernelGGL(linear_dlogits_kernel<true>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
+                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles);
+    } else {
+        allow_lds(linear_dlogits_kernel<false>, lds_bytes);
+        hipLaunchKernelGGL(linear_dlogits_kernel<false>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
+                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles);
+    }
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
 
 extern "C" int dssvae_onehot_sub(float* dL, int64_t ldd, const int64_t* target, int T, int64_t ignore_index,
-                                 const float* g, int M, int N, void* stream) {
-    if (!dL || !target || !g || M <= 0 || T <= 0) return DSSVAE_EINVAL;
+                                 const float* g, int M, int64_t n0, int64_t n1, float* colsum, void* stream) {
+    if (!dL || !target || !g || M <= 0 || T <= 0 || n1 <= n0) return DSSVAE_EINVAL;
     const int64_t total = (int64_t)M * T;
     hipLaunchKernelGGL(onehot_sub_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       dL, ldd, target, ignore_index, g, total, T, N);
+                       dL, ldd, target, ignore_index, g, total, T, n0, n1, colsum);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
 
 extern "C" int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream) {
     if (!X || !out || M <= 0 || N <= 0) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(256), 0, (hipStream_t)stream, X, ldx, M, N, out,
-                       accumulate);
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int col_blocks = (N + 63) / 64;
+    int row_blocks = max(1, min((M + 63) / 64, (4 * n_cus_cached() + col_blocks - 1) / col_blocks));
+    const int rpb = ((M + row_blocks - 1) / row_blocks + 3) / 4 * 4;
+    row_blocks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, s, X, ldx, M, N, out, rpb);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

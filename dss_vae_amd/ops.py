@@ -285,7 +285,15 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False):
     return lse, arg
 
 
-SLAB_BYTES = 128 << 20  # row-chunk slab of dlogits: sized to stay inside the 256 MiB Infinity Cache
+SLAB_BYTES = 128 << 20  # column-chunk slab of dlogits: sized to stay inside the 256 MiB Infinity Cache
+
+
+def _col_chunks(M, N):
+    """split the vocabulary into equal chunks of whole 128-column tiles whose [M, nc] slab fits SLAB_BYTES"""
+    nc_max = max(128, (SLAB_BYTES // (4 * M)) // 128 * 128)
+    n_chunks = (N + nc_max - 1) // nc_max
+    nc = ((N + n_chunks - 1) // n_chunks + 127) // 128 * 128
+    return nc
 
 
 class _LinearCEFn(Function):
@@ -318,6 +326,9 @@ class _LinearCEFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        """Per chunk of vocabulary columns: recompute dlogits into an Infinity-Cache-sized slab [M, nc]
+        (+ the bias gradient by column sums in the same kernel), subtract the one-hot part, then
+        dX += dL.W_chunk (dgrad, accumulating) and dW_chunk = dL^T.[xh|xe] (wgrad, written once)."""
         xh, xe, W, b, target, lse, cnt = ctx.saved_tensors
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         xh, ldh = _rows(xh)
@@ -327,6 +338,7 @@ class _LinearCEFn(Function):
             Ke = xe.size(1)
         else:
             lde, Ke, need_xe = 0, 0, False
+        K = Kh + Ke
         W, ldw = _rows(W)
         M, N = xh.size(0), W.size(0)
         T = target.size(1)
@@ -334,39 +346,37 @@ class _LinearCEFn(Function):
         g = g.contiguous()
         coef = (g * cnt).contiguous()
         g_mt = g.unsqueeze(1).expand(M, T).contiguous()
-        ldd = (N + 3) // 4 * 4
-        rows = max(128, min((M + 127) // 128 * 128, (SLAB_BYTES // (ldd * 4)) // 128 * 128))
-        slab = torch.empty(min(rows, M), ldd, device=dev, dtype=torch.float32)
-        dxh = torch.empty(M, Kh, device=dev, dtype=torch.float32) if need_xh else None
-        dxe = torch.empty(M, Ke, device=dev, dtype=torch.float32) if need_xe else None
-        dW = torch.empty(N, Kh + Ke, device=dev, dtype=torch.float32) if need_w else None
-        db = torch.empty(N, device=dev, dtype=torch.float32) if (need_b and b is not None) else None
+        nc = _col_chunks(M, N)
+        ldd = min(nc, (N + 3) // 4 * 4)
+        slab = torch.empty(M, ldd, device=dev, dtype=torch.float32)
+        need_x = need_xh or need_xe
+        dx = torch.empty(M, K, device=dev, dtype=torch.float32) if need_x else None
+        dW = torch.empty(N, K, device=dev, dtype=torch.float32) if need_w else None
+        db = torch.zeros(N, device=dev, dtype=torch.float32) if (need_b and b is not None) else None
+        xcat = None
+        if need_w:
+            xcat = xh if xe is None else torch.cat((xh, xe), dim=1)
         lib = L.load()
-        first = True
-        for m0 in range(0, M, rows):
-            mc = min(rows, M - m0)
-            xh_c = xh[m0:m0 + mc]
-            xe_c = xe[m0:m0 + mc] if xe is not None else None
-            dl = slab[:mc]
-            with _Span("linear_dlogits_kernel", 2.0 * mc * N * (Kh + Ke),
-                       4.0 * (mc * (Kh + Ke) + N * (Kh + Ke) + mc * N)):
-                L.check(lib.dssvae_linear_ce_dlogits(L.ptr(xh_c), ldh, Kh, L.ptr(xe_c), lde, Ke, L.ptr(W), ldw,
-                                                     L.ptr(b), L.ptr(lse[m0:]), L.ptr(coef[m0:]), mc, N, L.ptr(dl),
-                                                     ldd, L.stream()), "dssvae_linear_ce_dlogits")
-            L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(g_mt[m0:]), mc, N,
-                                          L.stream()), "dssvae_onehot_sub")
-            dlv = dl[:, :N]
-            if need_xh:
-                mm_nn(dlv, W[:, :Kh], out=dxh[m0:m0 + mc])
-            if need_xe:
-                mm_nn(dlv, W[:, Kh:], out=dxe[m0:m0 + mc])
+        for n0 in range(0, N, nc):
+            n1 = min(N, n0 + nc)
+            w = n1 - n0
+            Wc = W[n0:n1]
+            with _Span("linear_dlogits_kernel", 2.0 * M * w * K, 4.0 * (M * K + w * K + M * w)):
+                L.check(lib.dssvae_linear_ce_dlogits(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(Wc), ldw,
+                                                     None if b is None else C.c_void_p(b.data_ptr() + 4 * n0),
+                                                     L.ptr(lse), L.ptr(coef), M, w, L.ptr(slab), ldd,
+                                                     None if db is None else C.c_void_p(db.data_ptr() + 4 * n0),
+                                                     L.stream()), "dssvae_linear_ce_dlogits")
+            L.check(lib.dssvae_onehot_sub(L.ptr(slab), ldd, L.ptr(target), T, ctx.ignore, L.ptr(g_mt), M, n0, n1,
+                                          None if db is None else C.c_void_p(db.data_ptr() + 4 * n0), L.stream()),
+                    "dssvae_onehot_sub")
+            dlv = slab[:, :w]
+            if need_x:
+                mm_nn(dlv, Wc, out=dx, beta=0.0 if n0 == 0 else 1.0)
             if need_w:
-                mm_tn(dlv, xh_c, out=dW[:, :Kh], beta=0.0 if first else 1.0)
-                if xe is not None:
-                    mm_tn(dlv, xe_c, out=dW[:, Kh:], beta=0.0 if first else 1.0)
-            if db is not None:
-                colsum(dlv, out=db, accumulate=not first)
-            first = False
+                mm_tn(dlv, xcat, out=dW[n0:n1])
+        dxh = dx[:, :Kh] if need_xh else None
+        dxe = dx[:, Kh:] if need_xe else None
         return dxh, dxe, dW, db, None, None
 
 

@@ -45,6 +45,14 @@ int dssvae_gemm_f32(const float* A, int64_t lda, int trans_a, const int64_t* a_r
                     const float* B, int64_t ldb, int trans_b,
                     float* C, int64_t ldc, const float* bias,
                     int M, int N, int K, float alpha, float beta, void* stream);
+/* Same, with an explicit split of the K loop over `ksplit` workgroups per output tile (partials
+ * combined with fp32 atomic adds; needs beta in {0,1}; ksplit <= 0: chosen from the tile count so
+ * that small-M/N, large-K products -- the dgrad/wgrad shapes of the vocabulary projection and the
+ * GRU weight gradients -- still fill the chip).  dssvae_gemm_f32 is ksplit = 0. */
+int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64_t* a_rows,
+                           const float* B, int64_t ldb, int trans_b,
+                           float* C, int64_t ldc, const float* bias,
+                           int M, int N, int K, float alpha, float beta, int ksplit, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused vocabulary projection + online log-sum-exp (logits are never written).
@@ -72,17 +80,22 @@ int dssvae_picked_logit(const float* Xh, int64_t ldh, int Kh, const float* Xe, i
                         const float* W, int64_t ldw, const float* bias, const int64_t* target, int T,
                         int64_t ignore_index, int M, float* picked, void* stream);
 
-/* Backward, one row chunk: dL[m,n] = coef[m] * exp(logit[m,n] - lse[m]) for rows [0,M) of the
- * chunk, written to the caller's slab dL [M, ldd] (ldd >= N).  The caller then subtracts the
- * one-hot part (dssvae_onehot_sub) and runs dssvae_gemm_f32 for dX / dW / colsum for db.
+/* Backward, one chunk of the vocabulary (the caller passes W, bias offset to the chunk's first
+ * column and N = columns in the chunk; or all of it): dL[m,n] = coef[m] * exp(logit[m,n] - lse[m])
+ * written to the caller's slab dL [M, ldd] (ldd >= N); colsum (may be NULL) [N] += sum_m dL[m,n]
+ * (the softmax part of the bias gradient, accumulated with atomics: zero it first).  The caller
+ * then subtracts the one-hot part (dssvae_onehot_sub) and runs dssvae_gemm_f32 for dX / dW.
  * Replaces autograd of log_softmax+gather (decoder/rnn_decoder.py:94-102). */
 int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
                              const float* W, int64_t ldw, const float* bias, const float* lse,
-                             const float* coef, int M, int N, float* dL, int64_t ldd, void* stream);
+                             const float* coef, int M, int N, float* dL, int64_t ldd, float* colsum,
+                             void* stream);
 
-/* dL[m, target[m,t]] -= g[m,t] for every non-ignored target (atomic: targets may repeat). */
+/* For every non-ignored target in the chunk's column range [n0, n1):
+ * dL[m, target[m,t] - n0] -= g[m,t] and (colsum != NULL) colsum[target - n0] -= g[m,t]
+ * (atomic: targets may repeat). */
 int dssvae_onehot_sub(float* dL, int64_t ldd, const int64_t* target, int T, int64_t ignore_index,
-                      const float* g, int M, int N, void* stream);
+                      const float* g, int M, int64_t n0, int64_t n1, float* colsum, void* stream);
 
 /* out[n] (+)= sum_m X[m,n]  (bias gradients). */
 int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* out, int accumulate, void* stream);
