@@ -53,6 +53,7 @@ struct Stager {
     const float* p1; const float* p2; const int64_t* rows;
     int64_t ld1, ld2;
     int K1, K, Rtot, r0;
+    unsigned okmask;  // which staged registers hold in-range k (the k tail is zeroed when written to LDS)
 
     __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int K1_, const float* p2_, int64_t ld2_,
                                          const int64_t* rows_, int Rtot_, int r0_, int K_) {
@@ -77,25 +78,21 @@ struct Stager {
                 const int kc = ok ? k : 0;
                 const bool first = kc < K1;
                 const int off = first ? kc : kc - K1;
+                okmask = ok ? ~0u : 0u;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const float* src = (first ? b1[i] : b2[i]) + off;
-                    float4 t = *reinterpret_cast<const float4*>(src);
-                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[i] = t;
-                }
+                for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>((first ? b1[i] : b2[i]) + off);
             } else {
                 const int k = k0 + (threadIdx.x & 31);
                 const bool ok = k < K;
                 const int kc = ok ? k : 0;
                 const bool first = kc < K1;
                 const int off = first ? kc : kc - K1;
+                okmask = ok ? ~0u : 0u;
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
                     const int r = min(r0 + (int)(threadIdx.x >> 5) + 8 * e, Rtot - 1);
                     const int64_t ri = rows ? rows[r] : (int64_t)r;
-                    const float t = first ? p1[ri * ld1 + off] : p2[ri * ld2 + off];
-                    s[e] = ok ? t : 0.f;
+                    s[e] = first ? p1[ri * ld1 + off] : p2[ri * ld2 + off];
                 }
             }
         } else {
@@ -103,23 +100,24 @@ struct Stager {
                 constexpr int TPK = R / 4;          // threads per k row
                 constexpr int KSTEP = NTHREADS / TPK;
                 const int r4 = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
+                okmask = 0u;
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
                     const int k = k0 + (int)(threadIdx.x / TPK) + KSTEP * i;
                     const bool ok = k < K;
-                    float4 t = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
-                    if (!ok) t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    v[i] = t;
+                    okmask |= ok ? (1u << i) : 0u;
+                    v[i] = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
                 }
             } else {
                 constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
                 const int r = min(r0 + (int)(threadIdx.x % R), Rtot - 1);
+                okmask = 0u;
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
                     const int k = k0 + (int)(threadIdx.x / R) + KSTEP * e;
                     const bool ok = k < K;
-                    const float t = p1[(int64_t)(ok ? k : 0) * ld1 + r];
-                    s[e] = ok ? t : 0.f;
+                    okmask |= ok ? (1u << e) : 0u;
+                    s[e] = p1[(int64_t)(ok ? k : 0) * ld1 + r];
                 }
             }
         }
@@ -130,10 +128,12 @@ struct Stager {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    *reinterpret_cast<float4*>(img + ((threadIdx.x >> 3) + 32 * i) * LDK + 4 * (threadIdx.x & 7)) = v[i];
+                    *reinterpret_cast<float4*>(img + ((threadIdx.x >> 3) + 32 * i) * LDK + 4 * (threadIdx.x & 7)) =
+                        okmask ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
-                for (int e = 0; e < NS; ++e) img[((threadIdx.x >> 5) + 8 * e) * LDK + (threadIdx.x & 31)] = s[e];
+                for (int e = 0; e < NS; ++e)
+                    img[((threadIdx.x >> 5) + 8 * e) * LDK + (threadIdx.x & 31)] = okmask ? s[e] : 0.f;
             }
         } else {
             if (VEC) {
@@ -141,11 +141,13 @@ struct Stager {
                 constexpr int KSTEP = NTHREADS / TPK;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) = v[i];
+                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) =
+                        ((okmask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 constexpr int KSTEP = NTHREADS / R;
 #pragma unroll
-                for (int e = 0; e < NS; ++e) img[((threadIdx.x / R) + KSTEP * e) * (R + 4) + (threadIdx.x % R)] = s[e];
+                for (int e = 0; e < NS; ++e)
+                    img[((threadIdx.x / R) + KSTEP * e) * (R + 4) + (threadIdx.x % R)] = ((okmask >> e) & 1u) ? s[e] : 0.f;
             }
         }
     }
@@ -216,6 +218,7 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][jj], fb[j][jj], acc[i][j], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);  // keep the staged registers untouched (no vmcnt wait) until here
         if (more) {
             sa.store(As + (cur ^ 1) * AF);
             sb.store(Bs + (cur ^ 1) * BF);

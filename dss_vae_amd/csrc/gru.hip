@@ -4,17 +4,22 @@
 // layer, a task head).  Each instance is cut into (batch block of 64 rows) x (slice of 16 hidden
 // units); one 256-thread workgroup owns one cell of that grid for ALL timesteps:
 //   * its W_hh slice (3 gates x 16 units x H, fp32) is loaded into LDS once and stays resident;
-//   * per step each of its 4 waves multiplies 16 batch rows of h_{t-1} (B operand, streamed from
-//     the L2-resident exchange buffer as float4) with the resident slice (A operand, ds_read_b32)
-//     on v_mfma_f32_16x16x4_f32, then applies the fused gate math in registers;
-//   * the new 64x16 slice of h_t goes to a ping-pong exchange buffer; workgroups of the same
-//     (instance, batch block) meet on one monotonic arrival counter per step -- there is no
-//     grid-wide barrier, and independent instances / batch blocks never wait for each other.
-// Cross-workgroup visibility follows the agent-scope release / acquire recipe (producer: every
-// wave drains its stores, workgroup barrier, one lane release-fences and adds to the counter;
-// consumer: one lane polls relaxed, acquire-fences once, workgroup barrier, plain loads).
-// All workgroups must be co-resident: the host caps the grid at the CU count (1 workgroup per
-// CU); every spin is bounded and reports through an error word instead of hanging.
+//   * per step each of its 4 waves multiplies 16 batch rows of h_{t-1} (B operand) with the
+//     resident slice (A operand) on v_mfma_f32_16x16x4_f32, then applies the fused gate math in
+//     registers and stores its 16x16 piece of h_t;
+//   * the state is exchanged through a ping-pong buffer laid out [slice][row][16 units], so a
+//     workgroup publishes ONE contiguous 4 KB block and a reading wave takes 1 KB contiguous per
+//     slice; workgroups of the same (instance, batch block) meet on one monotonic arrival counter
+//     per step -- there is no grid-wide barrier, and independent instances / batch blocks never
+//     wait for each other.
+// Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first table row): EVERY byte of
+// the exchange buffer is stored write-through (buffer_store_dwordx4 sc1) and EVERY load of it is a
+// buffer_load_dwordx4 sc1 (bypasses the CU's L1), so no release / acquire cache maintenance is
+// needed: each storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup barrier joins
+// them, one lane adds to the counter (agent-scope atomic); the consumer's lane 0 polls the counter
+// with sc1 loads, then the workgroup barrier, then the sc1 loads.
+// All workgroups of a launch must be co-resident: the host caps the grid at the CU count (1
+// workgroup per CU); every spin is bounded and reports through an error word instead of hanging.
 //
 // Roofline: per step 2*B*H*3H flop on fp32 MFMA; in practice latency-bound by the step hand-off.
 #include "common.h"
@@ -24,14 +29,18 @@ namespace {
 constexpr int BB = 64;   // batch rows per workgroup (4 waves x 16 rows)
 constexpr int UU = 16;   // hidden units per workgroup (M of the 16x16x4 MFMA)
 constexpr int NTHR = 256;
-constexpr unsigned SPIN_LIMIT = 1u << 26;
+constexpr int CH = 8;    // exchange slices fetched per register chunk
+constexpr unsigned SPIN_LIMIT = 1u << 24;
 constexpr int CNT_STRIDE = 32;  // one 128-B line per counter
+constexpr int BLK = BB * UU;    // floats in one [64 rows][16 units] exchange block
+
+typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 
 struct FwdDev {
     dssvae_gru_fwd_inst in;
-    int wg_begin, n_slices, n_bblocks, H16;
+    int wg_begin, n_slices, n_bblocks;
     unsigned* counters;
-    float* hx;  // [2][B][H16]
+    float* hx;  // [2][n_bblocks][n_slices][64][16]
 };
 struct FwdArgs {
     FwdDev inst[DSSVAE_GRU_MAX_INST];
@@ -40,9 +49,9 @@ struct FwdArgs {
 };
 struct BwdDev {
     dssvae_gru_bwd_inst in;
-    int wg_begin, n_slices, n_bblocks, K16;  // K16 = roundup(3H,16)
+    int wg_begin, n_slices, n_bblocks;
     unsigned* counters;
-    float* gx;  // [2][B][K16]
+    float* gx;  // [2][n_bblocks][n_slices][3][64][16]
 };
 struct BwdArgs {
     BwdDev inst[DSSVAE_GRU_MAX_INST];
@@ -50,23 +59,30 @@ struct BwdArgs {
     unsigned* err;
 };
 
-__device__ __forceinline__ int lds_row(int k) { return (k & ~15) | ((k & 3) << 2) | ((k >> 2) & 3); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
+}
+__device__ __forceinline__ void st_sc1(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 16);
+}
 
+// every storing wave drains, the barrier joins them, one lane signals (no release fence: the
+// payload stores are write-through)
 __device__ __forceinline__ void publish(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// one lane polls (sc1 loads), then the barrier; the payload loads that follow are all sc1
 __device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* err) {
     if (threadIdx.x == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(0);
             if ((++spins & 1023u) == 0) {
                 if (spins > SPIN_LIMIT ||
                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
@@ -75,9 +91,8 @@ __device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* 
                 }
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __syncthreads();
 }
 
@@ -102,16 +117,28 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4], bool vec, 
     }
 }
 
+// acc[g] += W_g[16 units][16 k of chunk] . X[16 k][16 rows]; Wc: this chunk's LDS image [4 c][4 kq][16 j]
+// xv: the lane's 4 k-values (k = 4*kq + c) of its batch row
+template <int NG>
+__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, int gate_stride, f32x4 xv) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[g * gate_stride + c * 64], xv[c], acc[g], 0, 0, 0);
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [3][H16][16]
+    // Ws[g][slice s][c][kq][j] = whh[(g*H + u0 + j)*H + 16 s + 4 kq + c]
+    extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
     while (ii + 1 < args.n_inst && (int)blockIdx.x >= args.inst[ii + 1].wg_begin) ++ii;
     const FwdDev& d = args.inst[ii];
     const dssvae_gru_fwd_inst& in = d.in;
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
-    const int H = in.H, H16 = d.H16, T = in.T, B = in.B;
+    const int H = in.H, T = in.T, B = in.B, NS = d.n_slices;
     const int u0 = slice * UU;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -121,14 +148,15 @@ __global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
     const int n_ok = max(0, min(4, H - ub));          // how many of them exist
     unsigned* cnt = d.counters + (size_t)bblock * CNT_STRIDE;
     const bool vec_h = (H % 4) == 0;
+    const int gate_stride = NS * 256;
 
-    // resident weights: Ws[g][lds_row(k)][i] = whh[(g*H + u0 + i)*H + k]
-    for (int idx = threadIdx.x; idx < 3 * H16 * UU; idx += NTHR) {
-        const int g = idx / (H16 * UU), rem = idx % (H16 * UU);
-        const int i = rem / H16, k = rem % H16;  // k fastest: coalesced global reads
-        const int u = u0 + i;
+    for (int idx = threadIdx.x; idx < 3 * NS * 256; idx += NTHR) {
+        const int g = idx / (NS * 256), rem = idx % (NS * 256);
+        const int jj = rem / (NS * 16), k = rem % (NS * 16);  // k fastest: coalesced global reads
+        const int u = u0 + jj;
         const float w = (u < H && k < H) ? in.whh[(size_t)(g * H + u) * H + k] : 0.f;
-        Ws[(g * H16 + lds_row(k)) * UU + i] = w;
+        const int s = k >> 4, kk = k & 15;
+        Ws[g * gate_stride + s * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + jj] = w;
     }
     float bh[3][4];
 #pragma unroll
@@ -137,60 +165,71 @@ __global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
         for (int c = 0; c < 4; ++c) bh[g][c] = (c < n_ok) ? in.bhh[g * H + ub + c] : 0.f;
     const int len = (in.lengths && row_ok) ? in.lengths[b] : T;
 
-    // state 0 into the exchange buffer (pad columns are zero and stay zero)
+    // exchange buffers of this batch block: [2][NS][64][16]; this lane's piece of its own block
+    const unsigned half_bytes = (unsigned)NS * BLK * 4u;
+    float* hx0 = d.hx + (size_t)bblock * NS * BLK;
+    float* hx1 = hx0 + (size_t)d.n_bblocks * NS * BLK;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(hx0, half_bytes), rs1 = make_rsrc(hx1, half_bytes);
+    const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;  // same lane offset inside every slice block
+    const int own = slice * BLK * 4;
+
+    // state 0 into the exchange buffer (pad units and pad rows are zero and stay zero)
     float hcur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-        if (in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
-        store4(d.hx + (size_t)b * H16 + ub, hcur, true, 4);
-    }
+    if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
+    st_sc1((f32x4){hcur[0], hcur[1], hcur[2], hcur[3]}, rs0, voff, own);
     publish(cnt);
 
+    const float* Wl = Ws + kq * 16 + j;
     for (int step = 0; step < T; ++step) {
         const int t = in.reverse ? T - 1 - step : step;
-        const float* hin = d.hx + (size_t)(step & 1) * B * H16;
-        float* hout = d.hx + (size_t)((step + 1) & 1) * B * H16;
-        await(cnt, (unsigned)(step + 1) * d.n_slices, args.err);
+        const __amdgpu_buffer_rsrc_t rin = (step & 1) ? rs1 : rs0, rout = (step & 1) ? rs0 : rs1;
+        // the x-projection gates of this step do not depend on the hand-off: fetch them first
+        const size_t bt = (size_t)(row_ok ? b : 0) * T + t;
+        const float* xp = in.xproj + bt * in.ldx;
+        float xr[4], xz[4], xn[4];
+        const bool vec_x = vec_h && (in.ldx % 4) == 0;
+        load4(xr, xp + ub, vec_x, n_ok);
+        load4(xz, xp + H + ub, vec_x, n_ok);
+        load4(xn, xp + 2 * H + ub, vec_x, n_ok);
+
+        await(cnt, (unsigned)(step + 1) * NS, args.err);
 
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        const float* hrow = hin + (size_t)(row_ok ? b : 0) * H16 + 4 * kq;
-        const float* wl = Ws + kq * UU + j;
-#pragma unroll 2
-        for (int s = 0; s < H16; s += 16) {
-            float4 hv = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row_ok) hv = *reinterpret_cast<const float4*>(hrow + s);
-            const float hvv[4] = {hv.x, hv.y, hv.z, hv.w};
+        f32x4 cur[CH], nxt[CH];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float* w = wl + (s + 4 * c) * UU;
+        for (int i = 0; i < CH; ++i) cur[i] = ld_sc1(rin, voff, min(i, NS - 1) * BLK * 4);
+        for (int s0 = 0; s0 < NS; s0 += CH) {
+            if (s0 + CH < NS) {
 #pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[g * H16 * UU], hvv[c], acc[g], 0, 0, 0);
+                for (int i = 0; i < CH; ++i) nxt[i] = ld_sc1(rin, voff, min(s0 + CH + i, NS - 1) * BLK * 4);
             }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (s0 + i < NS) mfma_chunk<3>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
         }
         // fused gate math: lane holds units ub..ub+3 of batch row b (pad units keep writing zeros)
-        if (row_ok) {
-            const size_t bt = (size_t)b * T + t;
-            const float* xp = in.xproj + bt * in.ldx;
-            float xr[4], xz[4], xn[4];
-            const bool vec_x = vec_h && (in.ldx % 4) == 0;
-            load4(xr, xp + ub, vec_x, n_ok);
-            load4(xz, xp + H + ub, vec_x, n_ok);
-            load4(xn, xp + 2 * H + ub, vec_x, n_ok);
-            const bool live = t < len;
-            float r[4], z[4], n[4], hn[4], hnew[4], outv[4];
+        const bool live = row_ok && t < len;
+        float r[4], z[4], n[4], hn[4], hnew[4], outv[4];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                r[c] = sigm(xr[c] + acc[0][c] + bh[0][c]);
-                z[c] = sigm(xz[c] + acc[1][c] + bh[1][c]);
-                hn[c] = acc[2][c] + bh[2][c];
-                n[c] = tanhf(xn[c] + r[c] * hn[c]);
-                const float hv = (1.f - z[c]) * n[c] + z[c] * hcur[c];
-                hnew[c] = (c < n_ok) ? (live ? hv : hcur[c]) : 0.f;
-                outv[c] = live ? hv : 0.f;
-            }
-            store4(hout + (size_t)b * H16 + ub, hnew, true, 4);
+        for (int c = 0; c < 4; ++c) {
+            r[c] = sigm(xr[c] + acc[0][c] + bh[0][c]);
+            z[c] = sigm(xz[c] + acc[1][c] + bh[1][c]);
+            hn[c] = acc[2][c] + bh[2][c];
+            n[c] = tanhf(xn[c] + r[c] * hn[c]);
+            const float hv = (1.f - z[c]) * n[c] + z[c] * hcur[c];
+            hnew[c] = (c < n_ok && row_ok) ? (live ? hv : hcur[c]) : 0.f;
+            outv[c] = live ? hv : 0.f;
+        }
+        // hand the new state over first; the history stores below then overlap the peers' next step
+        if (step + 1 < T) {
+            st_sc1((f32x4){hnew[0], hnew[1], hnew[2], hnew[3]}, rout, voff, own);
+            publish(cnt);
+        }
+        if (row_ok) {
             store4(in.out + bt * in.ldo + ub, outv, vec_h && (in.ldo % 4) == 0, n_ok);
             if (in.gates) {
                 float* gs = in.gates + bt * 5 * H + ub;
@@ -200,24 +239,24 @@ __global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
                 store4(gs + 3 * H, hn, vec_h, n_ok);
                 store4(gs + 4 * H, hcur, vec_h, n_ok);
             }
-#pragma unroll
-            for (int c = 0; c < 4; ++c) hcur[c] = hnew[c];
         }
-        if (step + 1 < T) publish(cnt);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) hcur[c] = hnew[c];
     }
     if (row_ok && n_ok > 0 && in.h_last) store4(in.h_last + (size_t)b * H + ub, hcur, vec_h, n_ok);
 }
 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTHR) void gru_bwd_kernel(BwdArgs args) {
-    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [K16][16]: Ws[lds_row(c)][i] = whh[c][u0+i]
+    // chunk q = 3*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
+    extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
     while (ii + 1 < args.n_inst && (int)blockIdx.x >= args.inst[ii + 1].wg_begin) ++ii;
     const BwdDev& d = args.inst[ii];
     const dssvae_gru_bwd_inst& in = d.in;
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
-    const int H = in.H, K16 = d.K16, T = in.T, B = in.B, K = 3 * H;
+    const int H = in.H, T = in.T, B = in.B, K = 3 * H, NS = d.n_slices, NQ = 3 * NS;
     const int u0 = slice * UU;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -228,33 +267,38 @@ __global__ __launch_bounds__(NTHR) void gru_bwd_kernel(BwdArgs args) {
     unsigned* cnt = d.counters + (size_t)bblock * CNT_STRIDE;
     const bool vec_h = (H % 4) == 0;
 
-    for (int idx = threadIdx.x; idx < K16 * UU; idx += NTHR) {
-        const int c = idx / UU, i = idx % UU;  // i fastest: 16 consecutive floats of a W_hh row
-        const int u = u0 + i;
-        Ws[lds_row(c) * UU + i] = (c < K && u < H) ? in.whh[(size_t)c * H + u] : 0.f;
+    for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
+        const int q = idx >> 8, rem = idx & 255;
+        const int kk = rem >> 4, i = rem & 15;  // i fastest: 16 consecutive floats of a W_hh row
+        const int p = q / 3, g = q - 3 * p;
+        const int cu = 16 * p + kk, u = u0 + i;
+        const float w = (cu < H && u < H) ? in.whh[(size_t)(g * H + cu) * H + u] : 0.f;
+        Ws[q * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + i] = w;
     }
     const int len = (in.lengths && row_ok) ? in.lengths[b] : T;
     float dh[4] = {0.f, 0.f, 0.f, 0.f};
     if (row_ok && in.dh_last) load4(dh, in.dh_last + (size_t)b * H + ub, vec_h, n_ok);
-    // pad columns [3H, K16) of both exchange buffers must read as zero
-    if (slice == 0 && row_ok && K16 > K) {
-        for (int c = K + kq; c < K16; c += 4) {
-            d.gx[(size_t)b * K16 + c] = 0.f;
-            d.gx[(size_t)(B + b) * K16 + c] = 0.f;
-        }
-    }
+
+    const unsigned half_bytes = (unsigned)NQ * BLK * 4u;
+    float* gx0 = d.gx + (size_t)bblock * NQ * BLK;
+    float* gx1 = gx0 + (size_t)d.n_bblocks * NQ * BLK;
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(gx0, half_bytes), rs1 = make_rsrc(gx1, half_bytes);
+    const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;
+    const int own = slice * 3 * BLK * 4;
     __syncthreads();
 
+    const float* Wl = Ws + kq * 16 + j;
     for (int step = 0; step < T; ++step) {
         // backward walks the forward order in reverse
         const int fstep = T - 1 - step;
         const int t = in.reverse ? T - 1 - fstep : fstep;
-        float* gcur = d.gx + (size_t)(step & 1) * B * K16;
+        const __amdgpu_buffer_rsrc_t rcur = (step & 1) ? rs1 : rs0;
         float dhz[4] = {0.f, 0.f, 0.f, 0.f};
+        float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dgz[4] = {0.f, 0.f, 0.f, 0.f}, dgn[4] = {0.f, 0.f, 0.f, 0.f},
+              dgm[4] = {0.f, 0.f, 0.f, 0.f};
+        const size_t bt = (size_t)(row_ok ? b : 0) * T + t;
         if (row_ok && n_ok > 0) {
-            const size_t bt = (size_t)b * T + t;
             const bool live = t < len;
-            float dgr[4], dgz[4], dgn[4], dgm[4];
             if (live) {
                 float go[4] = {0.f, 0.f, 0.f, 0.f};
                 if (in.dout) load4(go, in.dout + bt * in.ldd + ub, vec_h && (in.ldd % 4) == 0, n_ok);
@@ -269,45 +313,57 @@ __global__ __launch_bounds__(NTHR) void gru_bwd_kernel(BwdArgs args) {
                 for (int c = 0; c < 4; ++c) {
                     const float g = dh[c] + go[c];
                     const float dn = g * (1.f - z[c]) * (1.f - n[c] * n[c]);
-                    dgn[c] = dn;
-                    dgz[c] = g * (hp[c] - n[c]) * z[c] * (1.f - z[c]);
-                    dgr[c] = dn * hn[c] * r[c] * (1.f - r[c]);
-                    dgm[c] = dn * r[c];
+                    const bool ok = c < n_ok;
+                    dgn[c] = ok ? dn : 0.f;
+                    dgz[c] = ok ? g * (hp[c] - n[c]) * z[c] * (1.f - z[c]) : 0.f;
+                    dgr[c] = ok ? dn * hn[c] * r[c] * (1.f - r[c]) : 0.f;
+                    dgm[c] = ok ? dn * r[c] : 0.f;
                     dhz[c] = g * z[c];
                 }
             } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c) { dgr[c] = dgz[c] = dgn[c] = dgm[c] = 0.f; dhz[c] = dh[c]; }
+                for (int c = 0; c < 4; ++c) dhz[c] = dh[c];
             }
+        }
+        // this slice's three gate blocks (pad units / pad rows publish zeros); hand over first, the
+        // dgx / dgh history stores then overlap the wait
+        st_sc1((f32x4){dgr[0], dgr[1], dgr[2], dgr[3]}, rcur, voff, own);
+        st_sc1((f32x4){dgz[0], dgz[1], dgz[2], dgz[3]}, rcur, voff, own + BLK * 4);
+        st_sc1((f32x4){dgm[0], dgm[1], dgm[2], dgm[3]}, rcur, voff, own + 2 * BLK * 4);
+        publish(cnt);
+        if (row_ok && n_ok > 0) {
             float* ox = in.dgx + bt * K + ub;
             float* oh = in.dgh + bt * K + ub;
             store4(ox, dgr, vec_h, n_ok); store4(ox + H, dgz, vec_h, n_ok); store4(ox + 2 * H, dgn, vec_h, n_ok);
             store4(oh, dgr, vec_h, n_ok); store4(oh + H, dgz, vec_h, n_ok); store4(oh + 2 * H, dgm, vec_h, n_ok);
-            float* ge = gcur + (size_t)b * K16 + ub;
-            store4(ge, dgr, false, n_ok); store4(ge + H, dgz, false, n_ok); store4(ge + 2 * H, dgm, false, n_ok);
         }
-        publish(cnt);
-        await(cnt, (unsigned)(step + 1) * d.n_slices, args.err);
+        await(cnt, (unsigned)(step + 1) * NS, args.err);
 
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        const float* grow = gcur + (size_t)(row_ok ? b : 0) * K16 + 4 * kq;
-        const float* wl = Ws + kq * UU + j;
-        for (int s = 0; s < K16; s += 32) {
-            float4 g0 = make_float4(0.f, 0.f, 0.f, 0.f), g1 = g0;
-            if (row_ok) {
-                g0 = *reinterpret_cast<const float4*>(grow + s);
-                if (s + 16 < K16) g1 = *reinterpret_cast<const float4*>(grow + s + 16);
-            }
-            const float a0[4] = {g0.x, g0.y, g0.z, g0.w}, a1[4] = {g1.x, g1.y, g1.z, g1.w};
+        f32x4 acc[3];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(s + 4 * c) * UU], a0[c], acc0, 0, 0, 0);
-                if (s + 16 < K16)
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[(s + 16 + 4 * c) * UU], a1[c], acc1, 0, 0, 0);
+        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 cur[CH], nxt[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) cur[i] = ld_sc1(rcur, voff, min(i, NQ - 1) * BLK * 4);
+        for (int q0 = 0; q0 < NQ; q0 += CH) {
+            if (q0 + CH < NQ) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) nxt[i] = ld_sc1(rcur, voff, min(q0 + CH + i, NQ - 1) * BLK * 4);
             }
+#pragma unroll
+            for (int i = 0; i < CH; ++i)
+                if (q0 + i < NQ) {
+                    // three independent accumulators in rotation hide the 40-cycle dependent latency
+                    const float* w = Wl + (q0 + i) * 256;
+                    f32x4& a = acc[i % 3];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * 64], cur[i][c], a, 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + acc0[c] + acc1[c];
+        for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + acc[0][c] + acc[1][c] + acc[2][c];
     }
     if (row_ok && n_ok > 0 && in.dh0) store4(in.dh0 + (size_t)b * H + ub, dh, vec_h, n_ok);
 }
@@ -319,8 +375,8 @@ struct Layout {
 
 inline int round16(int x) { return (x + 15) & ~15; }
 
-// mult = row width multiplier of the exchange buffer: 1 (forward: H) or 3 (backward: 3H)
-Layout plan(int n_inst, const int32_t* B, const int32_t* H, int mult_max) {
+// exchange buffers are sized for the backward pass (3 gate blocks per slice); forward uses a third
+Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     Layout L;
     size_t off = 256;  // error word + padding
     for (int i = 0; i < n_inst; ++i) {
@@ -331,7 +387,7 @@ Layout plan(int n_inst, const int32_t* B, const int32_t* H, int mult_max) {
     L.header_bytes = off;
     for (int i = 0; i < n_inst; ++i) {
         L.buf_off[i] = off;
-        off += (size_t)2 * B[i] * round16(mult_max * H[i]) * sizeof(float);
+        off += (size_t)2 * ((B[i] + BB - 1) / BB) * BB * 3 * round16(H[i]) * sizeof(float);
         off = (off + 255) & ~(size_t)255;
     }
     L.total_bytes = off;
@@ -352,7 +408,9 @@ int cu_count() {
 
 extern "C" int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host) {
     if (n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !B_host || !H_host) return DSSVAE_EINVAL;
-    return (int64_t)plan(n_inst, B_host, H_host, 3).total_bytes;
+    for (int i = 0; i < n_inst; ++i)
+        if (B_host[i] <= 0 || H_host[i] <= 0) return DSSVAE_EINVAL;
+    return (int64_t)plan(n_inst, B_host, H_host).total_bytes;
 }
 
 extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void* workspace, int64_t workspace_bytes,
@@ -366,25 +424,24 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
             return DSSVAE_EINVAL;
         Bs[i] = x.B; Hs[i] = x.H;
     }
-    const Layout L = plan(n_inst, Bs, Hs, 3);
+    const Layout L = plan(n_inst, Bs, Hs);
     if ((int64_t)L.total_bytes > workspace_bytes || !aligned16(workspace)) return DSSVAE_EINVAL;
     FwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
-    int wg = 0, max_h16 = 0;
+    int wg = 0, max_ns = 0;
     for (int i = 0; i < n_inst; ++i) {
         FwdDev& d = args.inst[i];
         d.in = inst[i];
-        d.H16 = round16(inst[i].H);
-        d.n_slices = d.H16 / UU;
+        d.n_slices = round16(inst[i].H) / UU;
         d.n_bblocks = (inst[i].B + BB - 1) / BB;
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
         d.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
-        if (d.H16 > max_h16) max_h16 = d.H16;
+        if (d.n_slices > max_ns) max_ns = d.n_slices;
     }
-    const int lds_bytes = 3 * max_h16 * UU * (int)sizeof(float);
+    const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
     if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(workspace, 0, L.header_bytes, s);
@@ -406,25 +463,24 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
             return DSSVAE_EINVAL;
         Bs[i] = x.B; Hs[i] = x.H;
     }
-    const Layout L = plan(n_inst, Bs, Hs, 3);
+    const Layout L = plan(n_inst, Bs, Hs);
     if ((int64_t)L.total_bytes > workspace_bytes || !aligned16(workspace)) return DSSVAE_EINVAL;
     BwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
-    int wg = 0, max_k16 = 0;
+    int wg = 0, max_ns = 0;
     for (int i = 0; i < n_inst; ++i) {
         BwdDev& d = args.inst[i];
         d.in = inst[i];
-        d.K16 = round16(3 * inst[i].H);
         d.n_slices = round16(inst[i].H) / UU;
         d.n_bblocks = (inst[i].B + BB - 1) / BB;
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
         d.gx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
-        if (d.K16 > max_k16) max_k16 = d.K16;
+        if (d.n_slices > max_ns) max_ns = d.n_slices;
     }
-    const int lds_bytes = max_k16 * UU * (int)sizeof(float);
+    const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
     if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemsetAsync(workspace, 0, L.header_bytes, s);

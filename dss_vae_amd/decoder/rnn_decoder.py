@@ -54,7 +54,7 @@ class RNNDecoder(RNNBase):
                 x = x * ops.dropout_mask(tuple(x.shape), self.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
             wih, whh, bih, bhh = self.rnn.layer_params(layer)
             (x,), (h,) = ops.gru_layer([dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=h0[layer],
-                                             group=0, col=0)], save=torch.is_grad_enabled())
+                                             group=0, col=0)])
             hl.append(h)
         return x, emb, torch.stack(hl, 0)
 
@@ -132,34 +132,57 @@ class RNNDecoder(RNNBase):
         return encoder_hidden
 
 
+def prepare_job(job):
+    """embedding rows of a scoring job, looked up NOW (records autograd under the current
+    requires_grad flags: EnhanceSyntaxVAE freezes its adversaries, and with them the shared
+    embeddings, between the main heads and the adversary heads)."""
+    if "_emb" not in job:
+        if job.get("no_grad"):
+            with torch.no_grad():
+                job["_emb"] = lookup(job["dec"].embedding, job["inputs"][:, :-1].contiguous(), GLOBAL_SEEDS)
+        else:
+            job["_emb"] = lookup(job["dec"].embedding, job["inputs"][:, :-1].contiguous(), GLOBAL_SEEDS)
+    return job
+
+
 def score_many(jobs):
-    """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word}.
-    -> list of per-sentence log-probabilities [B], one per job."""
+    """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word, no_grad}.
+    -> list of per-sentence log-probabilities [B], one per job.  All jobs advance layer by layer
+    together, so their recurrences share persistent GRU launches; a `no_grad` job (an adversary
+    that is only evaluated) is forward-only inside the shared launches."""
     n_layers = jobs[0]["dec"].n_layers
     assert all(j["dec"].n_layers == n_layers for j in jobs)
+    grad_on = torch.is_grad_enabled()
     embs, xs = [], []
     for j in jobs:
-        e = lookup(j["dec"].embedding, j["inputs"][:, :-1].contiguous(), GLOBAL_SEEDS)
+        e = prepare_job(j)["_emb"]
         embs.append(e)
         xs.append(e)
     for layer in range(n_layers):
         insts = []
         for k, j in enumerate(jobs):
             dec, x = j["dec"], xs[k]
-            if layer > 0 and dec.training and dec.rnn_droprate > 0.0:
-                x = x * ops.dropout_mask(tuple(x.shape), dec.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
-            wih, whh, bih, bhh = dec.rnn.layer_params(layer)
-            insts.append(dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=j["h0"][layer], group=k, col=0))
-        xs, _ = ops.gru_layer(insts, save=torch.is_grad_enabled())
+            ng = bool(j.get("no_grad")) or not grad_on
+            with torch.set_grad_enabled(not ng):
+                if layer > 0 and dec.training and dec.rnn_droprate > 0.0:
+                    x = x * ops.dropout_mask(tuple(x.shape), dec.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
+                wih, whh, bih, bhh = dec.rnn.layer_params(layer)
+                h0 = j["h0"][layer]
+                if ng:
+                    whh, bhh, h0 = whh.detach(), bhh.detach(), h0.detach()
+                insts.append(dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=h0, group=k, col=0,
+                                  save=not ng))
+        xs, _ = ops.gru_layer(insts)
     res = []
     for k, j in enumerate(jobs):
         dec = j["dec"]
         B, T, H = xs[k].shape
         gold = j["targets"][:, 1:].reshape(-1)
-        nll = ops.linear_ce(xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1), dec.out.weight, dec.out.bias, gold,
-                            dec.pad_id)
-        logp = -nll.view(B, T).sum(1)
-        if j.get("norm_by_word"):
-            logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())
+        with torch.set_grad_enabled(grad_on and not j.get("no_grad")):
+            nll = ops.linear_ce(xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1), dec.out.weight, dec.out.bias,
+                                gold, dec.pad_id)
+            logp = -nll.view(B, T).sum(1)
+            if j.get("norm_by_word"):
+                logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())
         res.append(logp)
     return res

@@ -403,22 +403,25 @@ def linear_argmax(xh, xe, W, b):
 # Persistent GRU
 # ----------------------------------------------------------------------------------------------
 def _pack(insts):
-    """Split instances into launches of <= 8 instances whose workgroups are co-resident."""
+    """Group instances (B, H, T) into persistent launches whose workgroups are co-resident (one per
+    CU) and that hold <= 8 instances, longest recurrences first (first-fit decreasing on T): a
+    launch lasts as long as its longest instance, so equal lengths share launches."""
     cus = n_cus()
-    launches, cur, wg = [], [], 0
-    for i, (B, H) in enumerate(insts):
+    launches = []  # [indices, workgroups]
+    for i in sorted(range(len(insts)), key=lambda i: -insts[i][2]):
+        B, H, _ = insts[i]
         need = ((B + 63) // 64) * ((H + 15) // 16)
         if need > cus:
             raise RuntimeError("GRU instance B=%d H=%d needs %d workgroups > %d CUs: not supported by the "
                                "persistent kernel yet" % (B, H, need, cus))
-        if cur and (wg + need > cus or len(cur) == L.GRU_MAX_INST):
-            launches.append(cur)
-            cur, wg = [], 0
-        cur.append(i)
-        wg += need
-    if cur:
-        launches.append(cur)
-    return launches
+        for l in launches:
+            if l[1] + need <= cus and len(l[0]) < L.GRU_MAX_INST:
+                l[0].append(i)
+                l[1] += need
+                break
+        else:
+            launches.append([[i], need])
+    return [sorted(l[0]) for l in launches]
 
 
 def _workspace(Bs, Hs, dev):
@@ -442,6 +445,7 @@ class _GruFn(Function):
 
     @staticmethod
     def forward(ctx, meta, *tensors):
+        ctx.set_materialize_grads(False)
         n = meta["n"]
         xs, ws, bs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
         L.require_cuda(*xs)
@@ -454,14 +458,14 @@ class _GruFn(Function):
             Bg, Tg = BT[meta["group"].index(g)]
             outs.append(torch.empty(Bg, Tg, wdt, device=dev, dtype=torch.float32))
         hl = [torch.empty(BT[i][0], H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
-        save = meta["save"]
-        gates = [torch.empty(BT[i][0], BT[i][1], 5 * H, device=dev, dtype=torch.float32) if save else None
+        save = meta["save"]  # per instance
+        gates = [torch.empty(BT[i][0], BT[i][1], 5 * H, device=dev, dtype=torch.float32) if save[i] else None
                  for i, H in enumerate(Hs)]
         ws = [w.contiguous() for w in ws]
         bs = [b.contiguous() for b in bs]
         h0s = [None if h.numel() == 0 else h.contiguous() for h in h0s]
         lib = L.load()
-        for launch in _pack([(BT[i][0], Hs[i]) for i in range(n)]):
+        for launch in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in range(n)]):
             arr = (L.GruFwdInst * len(launch))()
             for k, i in enumerate(launch):
                 o = outs[meta["group"][i]]
@@ -475,7 +479,7 @@ class _GruFn(Function):
                     int(meta["reverse"][i]))
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
-            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save else 4) for i in launch)
+            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save[i] else 4) for i in launch)
             with _Span("gru_fwd_kernel", fl, by):
                 L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
             if meta.get("check"):
@@ -483,6 +487,7 @@ class _GruFn(Function):
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
         ctx.h0_none = [h is None for h in h0s]
         ctx.save_for_backward(*ws, *[h for h in h0s if h is not None], *[g for g in gates if g is not None])
+        ctx.gate_slot = [sum(1 for g in gates[:i] if g is not None) if gates[i] is not None else -1 for i in range(n)]
         return (*outs, *hl)
 
     @staticmethod
@@ -493,16 +498,23 @@ class _GruFn(Function):
         saved = list(ctx.saved_tensors)
         ws = saved[:n]
         n_h0 = sum(1 for x in ctx.h0_none if not x)
-        gates = saved[n + n_h0:]
+        gsaved = saved[n + n_h0:]
+        gates = [gsaved[k] if k >= 0 else None for k in ctx.gate_slot]
         dev = ws[0].device
         douts = [None if g is None else g.contiguous() for g in grads[:ng]]
         dhl = [None if g is None else g.contiguous() for g in grads[ng:]]
         lengths = meta["lengths"]
-        dgx = [torch.empty(BT[i][0], BT[i][1], 3 * H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
-        dgh = [torch.empty(BT[i][0], BT[i][1], 3 * H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
-        dh0 = [torch.empty(BT[i][0], H, device=dev, dtype=torch.float32) for i, H in enumerate(Hs)]
+        # instances that saved no history (forward-only heads) take no part in the backward launches
+        live = [i for i in range(n) if gates[i] is not None and
+                (douts[meta["group"][i]] is not None or dhl[i] is not None)]
+        dgx, dgh, dh0 = [None] * n, [None] * n, [None] * n
+        for i in live:
+            dgx[i] = torch.empty(BT[i][0], BT[i][1], 3 * Hs[i], device=dev, dtype=torch.float32)
+            dgh[i] = torch.empty(BT[i][0], BT[i][1], 3 * Hs[i], device=dev, dtype=torch.float32)
+            dh0[i] = torch.empty(BT[i][0], Hs[i], device=dev, dtype=torch.float32)
         lib = L.load()
-        for launch in _pack([(BT[i][0], Hs[i]) for i in range(n)]):
+        for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live]):
+            launch = [live[k] for k in launch_]
             arr = (L.GruBwdInst * len(launch))()
             for k, i in enumerate(launch):
                 do = douts[meta["group"][i]]
@@ -521,6 +533,9 @@ class _GruFn(Function):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         out = [None]
         for i in range(n):
+            if dgx[i] is None:
+                out += [None, None, None, None]
+                continue
             need = ctx.needs_input_grad[1 + 4 * i: 5 + 4 * i]
             H = Hs[i]
             rows = BT[i][0] * BT[i][1]
@@ -531,14 +546,17 @@ class _GruFn(Function):
         return tuple(out)
 
 
-def gru_layer(insts, lengths=None, save=True, check=False):
+def gru_layer(insts, lengths=None, save=None, check=False):
     """Run independent GRU recurrences in as few persistent launches as fit the chip.
 
     insts: list of dicts {xproj [B,T,3H] (may be a column view), whh [3H,H], bhh [3H], h0 [B,H] or None,
-    reverse: bool, group: int, col: int}.  Instances of one group write disjoint column ranges
+    reverse: bool, group: int, col: int, save: bool (default: the `save` argument; False = forward-only
+    instance, no history kept)}.  Instances of one group write disjoint column ranges
     [col, col+H) of that group's output [B,T,width].  lengths: int32 device tensor [B] or None.
     Returns (list of group outputs, list of per-instance final states)."""
     n = len(insts)
+    if save is None:
+        save = torch.is_grad_enabled()
     groups = sorted(set(i["group"] for i in insts))
     width = [0] * len(groups)
     for i in insts:
@@ -548,7 +566,7 @@ def gru_layer(insts, lengths=None, save=True, check=False):
     empty = torch.empty(0, device=dev)
     meta = dict(n=n, group=[groups.index(i["group"]) for i in insts], col=[i["col"] for i in insts],
                 reverse=[bool(i.get("reverse", False)) for i in insts], lengths=lengths, group_width=width,
-                save=save, check=check)
+                save=[bool(i.get("save", save)) for i in insts], check=check)
     flat = []
     for i in insts:
         flat += [i["xproj"], i["whh"], i["bhh"], empty if i.get("h0") is None else i["h0"]]

@@ -4,7 +4,7 @@ detach()/reload(), :573-579) so gradient reaches the latents but not the adversa
 enters 'Loss' only when train_iter > warm_up (:333)."""
 import torch
 
-from ..decoder.rnn_decoder import score_many
+from ..decoder.rnn_decoder import prepare_job, score_many
 from ..utils.nn_funcs import wd_anneal_function
 from .syntax_vae import BridgeMLP, BridgeRNN, TwoEncoderVAE
 
@@ -75,8 +75,12 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
         return jobs, names
 
     def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=()):
+        """adversary terms; `extra_jobs` (already prepared main-head jobs) ride in the same persistent
+        GRU launches, their log-probs are returned second."""
         a = self.args
         jobs, names = self._adv_jobs(syn_h, sem_h, syn_tgt, sem_tgt)
+        for j in jobs:
+            prepare_job(j)
         res = score_many(list(extra_jobs) + jobs) if (jobs or extra_jobs) else []
         ne = len(extra_jobs)
         d = {"sem_to_syn": 0.0, "sem_to_sent": 0.0, "syn_to_sent": 0.0,
@@ -100,16 +104,16 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
             else:
                 ret["dis syn"], ret["dis sem"] = d["syn_to_sem"], d["sem_to_syn"]
             return ret
-        # same order as the reference: main decoder + multitask heads are recorded first, THEN the
-        # adversaries are frozen (this also flips requires_grad of the shared src/tgt embeddings, a
-        # reference quirk pinned by the golden 'nograd' lists), then the adversaries run.
-        main_jobs = [self._main_job(ret, tgt_var), self.mul_syn.job(syn_h, syn_var)]
-        rec, tree = score_many(main_jobs)
+        # same order as the reference: the main decoder + multitask heads read their (shared)
+        # embeddings first, THEN the adversaries are frozen (this also flips requires_grad of the
+        # shared src/tgt embeddings, a reference quirk pinned by the golden 'nograd' lists), then the
+        # adversaries read theirs.  The recurrences of all five sequence heads then share launches.
+        main_jobs = [prepare_job(self._main_job(ret, tgt_var)), prepare_job(self.mul_syn.job(syn_h, syn_var))]
         mul_sem_loss = a.mul_sem * self.mul_sem.forward(hidden=sem_h, tgt_var=tgt_var)
         if self.training:
             for n in self.ADVERSARIES:
                 getattr(self, n).detach()
-        d, _ = self._dis_terms(syn_h, sem_h, syn_var, tgt_var)
+        d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs)
         if a.infer_weight > 0.0:
             adv_for_syn = a.syn_to_sem * d["syn_to_sem"] + a.infer_weight * a.syn_to_sent * d["syn_to_sent"]
             adv_for_sem = a.sem_to_syn * d["sem_to_syn"] + a.infer_weight * a.sem_to_sent * d["sem_to_sent"]

@@ -213,9 +213,10 @@ class SyntaxVAE(TwoEncoderVAE):
         self.sem_adv = BridgeMLP(args, vocab, te, td)
         self.sem_infer = BridgeRNN(args, vocab, te, td, self.src_embed if share else None, "src")
 
-    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=()):
+    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=(), no_grad=False):
         """the four adversary heads; sequence heads share persistent launches (plus extra_jobs,
-        whose log-probs are returned last)."""
+        whose log-probs are returned last).  no_grad: the adversaries are only evaluated (the
+        reference runs them under torch.no_grad() in train mode, syntax_vae.py:322-324)."""
         a = self.args
         jobs, names = [], []
         if a.adv_syn > 0.0:
@@ -225,8 +226,11 @@ class SyntaxVAE(TwoEncoderVAE):
                 jobs.append(self.syn_infer.job(syn_h, sem_tgt)); names.append("adv_syn_inf")
             if a.inf_sem > 0.0:
                 jobs.append(self.sem_infer.job(sem_h, sem_tgt)); names.append("adv_sem_inf")
+        for j in jobs:
+            j["no_grad"] = no_grad
         res = score_many(jobs + list(extra_jobs)) if jobs or extra_jobs else []
-        d = {"adv_syn_sup": 0.0, "adv_sem_sup": self.sem_adv(syn_h, sem_tgt) if a.adv_sem > 0.0 else 0.0}
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not no_grad):
+            d = {"adv_syn_sup": 0.0, "adv_sem_sup": self.sem_adv(syn_h, sem_tgt) if a.adv_sem > 0.0 else 0.0}
         if a.infer_weight > 0.0:
             d.update(adv_syn_inf=0.0, adv_sem_inf=0.0)
         for n, r in zip(names, res):
@@ -253,12 +257,8 @@ class SyntaxVAE(TwoEncoderVAE):
                 ret["dis syn"], ret["dis sem"] = d["adv_syn_sup"], d["adv_sem_sup"]
             return ret
         main_jobs = [self._main_job(ret, tgt_var), self.sup_syn.job(syn_h, syn_var)]
-        if self.training:
-            rec, tree = score_many(main_jobs)
-            with torch.no_grad():
-                d, _ = self._dis_terms(syn_h, sem_h, syn_var, tgt_var)
-        else:
-            d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs)
+        d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs,
+                                         no_grad=self.training)
         adv_syn, adv_sem = self._adv_weights(d)
         mul_syn = self.args.mul_syn * (-tree)
         mul_sem = self.args.mul_sem * self.sup_sem(sem_h, tgt_var)
