@@ -24,7 +24,10 @@
 
 namespace {
 
-constexpr int BK = 32, NTHREADS = 256;
+#ifndef GEMM_BK
+#define GEMM_BK 32
+#endif
+constexpr int BK = GEMM_BK, NTHREADS = 256;
 constexpr int LDK = BK + 4;
 constexpr float NEG_BIG = -3.0e38f;
 
@@ -44,8 +47,11 @@ constexpr int lds_floats() { return 2 * (img_floats(TA, 64 * WM) + img_floats(TB
 // ---- global -> register -> LDS staging of one operand tile (R rows x 32 k) -----------------------
 template <bool TRANS, bool VEC, int R>
 struct Stager {
-    static constexpr int NV = R / 32;   // float4 per thread (VEC)
-    static constexpr int NS = R / 8;    // floats per thread (scalar)
+    static constexpr int NV = R * BK / 1024;  // float4 per thread (VEC)
+    static constexpr int NS = R * BK / 256;   // floats per thread (scalar)
+    static constexpr int TPR = BK / 4;        // k-contiguous image: threads per row (VEC)
+    static constexpr int RPP = NTHREADS / TPR;   // rows per pass (VEC)
+    static constexpr int RPS = NTHREADS / BK;    // rows per pass (scalar)
     float4 v[VEC ? NV : 1];
     float s[VEC ? 1 : NS];
     const float* b1[(!TRANS && VEC) ? NV : 1];
@@ -62,7 +68,7 @@ struct Stager {
         if (!TRANS && VEC) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int r = min(r0 + (int)(threadIdx.x >> 3) + 32 * i, Rtot - 1);
+                const int r = min(r0 + (int)(threadIdx.x / TPR) + RPP * i, Rtot - 1);
                 const int64_t ri = rows ? rows[r] : (int64_t)r;
                 b1[i] = p1 + ri * ld1;
                 b2[i] = p2 + ri * ld2;
@@ -73,7 +79,7 @@ struct Stager {
     __device__ __forceinline__ void load(int k0) {
         if (!TRANS) {
             if (VEC) {
-                const int k = k0 + 4 * (threadIdx.x & 7);
+                const int k = k0 + 4 * (threadIdx.x % TPR);
                 const bool ok = k < K;
                 const int kc = ok ? k : 0;
                 const bool first = kc < K1;
@@ -82,7 +88,7 @@ struct Stager {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>((first ? b1[i] : b2[i]) + off);
             } else {
-                const int k = k0 + (threadIdx.x & 31);
+                const int k = k0 + (threadIdx.x % BK);
                 const bool ok = k < K;
                 const int kc = ok ? k : 0;
                 const bool first = kc < K1;
@@ -90,7 +96,7 @@ struct Stager {
                 okmask = ok ? ~0u : 0u;
 #pragma unroll
                 for (int e = 0; e < NS; ++e) {
-                    const int r = min(r0 + (int)(threadIdx.x >> 5) + 8 * e, Rtot - 1);
+                    const int r = min(r0 + (int)(threadIdx.x / BK) + RPS * e, Rtot - 1);
                     const int64_t ri = rows ? rows[r] : (int64_t)r;
                     s[e] = first ? p1[ri * ld1 + off] : p2[ri * ld2 + off];
                 }
@@ -128,12 +134,12 @@ struct Stager {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    *reinterpret_cast<float4*>(img + ((threadIdx.x >> 3) + 32 * i) * LDK + 4 * (threadIdx.x & 7)) =
+                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + 4 * (threadIdx.x % TPR)) =
                         okmask ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
-                    img[((threadIdx.x >> 5) + 8 * e) * LDK + (threadIdx.x & 31)] = okmask ? s[e] : 0.f;
+                    img[((threadIdx.x / BK) + RPS * e) * LDK + (threadIdx.x % BK)] = okmask ? s[e] : 0.f;
             }
         } else {
             if (VEC) {
@@ -203,20 +209,31 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
         }
         const float* Ab = As + cur * AF;
         const float* Bb = Bs + cur * BF;
+        // fragments of group g+1 are fetched while group g multiplies (explicit register double buffer)
+        float fa[2][WM][4], fb[2][WN][4];
+#pragma unroll
+        for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[0][i], Ab, arow + 32 * i, 0, h);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[0][j], Bb, brow + 32 * j, 0, h);
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
-            float fa[WM][4], fb[WN][4];
+            const int c = g & 1, n = c ^ 1;
+            if (g + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[i], Ab, arow + 32 * i, g, h);
+                for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
 #pragma unroll
-            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[j], Bb, brow + 32 * j, g, h);
+                for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
+            }
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][jj], fb[j][jj], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
+            // scheduling order inside the group: the next group's LDS reads first, then this group's MFMAs
+            if (g + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, WM * (TA ? 4 : 1) + WN * (TB ? 4 : 1), 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
         }
         __builtin_amdgcn_sched_barrier(0);  // keep the staged registers untouched (no vmcnt wait) until here
         if (more) {
