@@ -297,12 +297,13 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
 }
 
 // ---- LSE (optionally with argmax) ----------------------------------------------------------------
-template <bool ARG, bool VEC>
+template <bool ARG, bool VEC, bool STORE>
 __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
                                                                int N, int K, int n_split, int tiles_per_split,
                                                                int tiles_n, float* __restrict__ part_max,
                                                                float* __restrict__ part_sum,
-                                                               int64_t* __restrict__ part_arg) {
+                                                               int64_t* __restrict__ part_arg,
+                                                               float* __restrict__ logits, int64_t ldl) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128;
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
@@ -330,6 +331,14 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
             for (int r = 0; r < 16; ++r) {
                 const float x0 = ok0 ? acc[mt][0][r] + b0 : NEG_BIG;
                 const float x1 = ok1 ? acc[mt][1][r] + b1 : NEG_BIG;
+                if (STORE) {  // side output: the logits of this row chunk into the cache-resident slab
+                    const int m = m0 + acc_row<2>(mt, r);
+                    if (m < M) {
+                        float* row = logits + (int64_t)m * ldl;
+                        if (ok0) row[c0] = x0;
+                        if (ok1) row[c1] = x1;
+                    }
+                }
                 const float mo = rm[mt][r];
                 const float mn = fmaxf(mo, fmaxf(x0, x1));
                 rs[mt][r] = rs[mt][r] * __expf(mo - mn) + __expf(x0 - mn) + __expf(x1 - mn);
@@ -439,6 +448,42 @@ __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, 
         if ((threadIdx.x & 63) < 32) {
             if (ok0) unsafeAtomicAdd(colsum + c0, s0);
             if (ok1) unsafeAtomicAdd(colsum + c1, s1);
+        }
+    }
+}
+
+// in place on the logits slab: x[m,n] <- coef[m] * exp(x[m,n] - lse[m]); colsum[n] += column sums.
+// block = 256 threads x 4 columns, ROWS rows per block
+__global__ void softmax_grad_kernel(float* __restrict__ X, int64_t ldx, const float* __restrict__ lse,
+                                    const float* __restrict__ coef, int M, int N, float* __restrict__ colsum,
+                                    int rows_per_block) {
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    const int m_begin = blockIdx.y * rows_per_block, m_end = min(M, m_begin + rows_per_block);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (n + 3 < N) {
+        for (int m = m_begin; m < m_end; ++m) {
+            const float l = lse[m], c = coef[m];
+            float4* p = reinterpret_cast<float4*>(X + (int64_t)m * ldx + n);
+            float4 v = *p;
+            v.x = c * __expf(v.x - l); v.y = c * __expf(v.y - l); v.z = c * __expf(v.z - l); v.w = c * __expf(v.w - l);
+            *p = v;
+            s0 += v.x; s1 += v.y; s2 += v.z; s3 += v.w;
+        }
+        if (colsum) {
+            unsafeAtomicAdd(colsum + n, s0); unsafeAtomicAdd(colsum + n + 1, s1);
+            unsafeAtomicAdd(colsum + n + 2, s2); unsafeAtomicAdd(colsum + n + 3, s3);
+        }
+    } else {
+        for (int j = 0; n + j < N; ++j) {
+            float sj = 0.f;
+            for (int m = m_begin; m < m_end; ++m) {
+                float* p = X + (int64_t)m * ldx + n + j;
+                const float v = coef[m] * __expf(*p - lse[m]);
+                *p = v;
+                sj += v;
+            }
+            if (colsum) unsafeAtomicAdd(colsum + n + j, sj);
         }
     }
 }
@@ -593,11 +638,12 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
 extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
                                      const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
                                      float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
-                                     void* stream) {
+                                     float* logits, int64_t ldl, void* stream) {
     if (!Xh || !W || !part_max || !part_sum || M <= 0 || N <= 0 || Kh <= 0 || Ke < 0 || n_split <= 0)
         return DSSVAE_EINVAL;
     if (Ke > 0 && !Xe) return DSSVAE_EINVAL;
     if (want_argmax && !part_arg) return DSSVAE_EINVAL;
+    if (logits && (ldl < N || want_argmax)) return DSSVAE_EINVAL;
     bool vec;
     OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke, &vec);
     OpB b;
@@ -608,14 +654,16 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
     const int tps = (tiles_n + n_split - 1) / n_split;
     hipStream_t s = (hipStream_t)stream;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
-#define GO(ARG, VEC)                                                                                             \
-    do {                                                                                                         \
-        allow_lds(linear_lse_kernel<ARG, VEC>, lds_bytes);                                                       \
-        hipLaunchKernelGGL((linear_lse_kernel<ARG, VEC>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes, s, \
-                           a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg);      \
+#define GO(ARG, VEC, ST)                                                                                          \
+    do {                                                                                                          \
+        allow_lds(linear_lse_kernel<ARG, VEC, ST>, lds_bytes);                                                    \
+        hipLaunchKernelGGL((linear_lse_kernel<ARG, VEC, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes, \
+                           s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg,     \
+                           logits, ldl);                                                                          \
     } while (0)
-    if (want_argmax) { if (vec) GO(true, true); else GO(true, false); }
-    else { if (vec) GO(false, true); else GO(false, false); }
+    if (logits) { if (vec) GO(false, true, true); else GO(false, false, true); }
+    else if (want_argmax) { if (vec) GO(true, true, false); else GO(true, false, false); }
+    else { if (vec) GO(false, true, false); else GO(false, false, false); }
 #undef GO
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
@@ -663,6 +711,19 @@ extern "C" int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, co
         hipLaunchKernelGGL(linear_dlogits_kernel<false>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
                            a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles);
     }
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_softmax_grad_inplace(float* X, int64_t ldx, const float* lse, const float* coef, int M, int N,
+                                           float* colsum, void* stream) {
+    if (!X || !lse || !coef || M <= 0 || N <= 0 || ldx < N || (ldx % 4) != 0 || !aligned16(X)) return DSSVAE_EINVAL;
+    const int col_blocks = (N + 1023) / 1024;
+    int row_blocks = max(1, min((M + 15) / 16, (8 * n_cus_cached() + col_blocks - 1) / col_blocks));
+    const int rpb = (M + row_blocks - 1) / row_blocks;
+    row_blocks = (M + rpb - 1) / rpb;
+    hipLaunchKernelGGL(softmax_grad_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, (hipStream_t)stream, X, ldx,
+                       lse, coef, M, N, colsum, rpb);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

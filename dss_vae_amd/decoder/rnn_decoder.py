@@ -37,10 +37,11 @@ class RNNDecoder(RNNBase):
         self.embedding.weight.requires_grad = update_embedding
 
     # ---- teacher-forced scoring (fused) ------------------------------------------------------
-    def score_inputs(self, inputs, targets, encoder_hidden, norm_by_word=False):
-        """log p(targets[:,1:] | inputs[:,:-1], h0) per sentence, [B]."""
+    def score_inputs(self, inputs, targets, encoder_hidden, norm_by_word=False, uniform=False):
+        """log p(targets[:,1:] | inputs[:,:-1], h0) per sentence, [B].  uniform=True: the caller only
+        ever sums the result with one common weight (see ops._LinearCEFn)."""
         return score_many([dict(dec=self, inputs=inputs, targets=targets, h0=encoder_hidden,
-                                norm_by_word=norm_by_word)])[0]
+                                norm_by_word=norm_by_word, uniform=uniform)])[0]
 
     def score(self, inputs, encoder_hidden, encoder_outputs=None, norm_by_word=False):
         return self.score_inputs(inputs, inputs, encoder_hidden, norm_by_word)
@@ -146,7 +147,7 @@ def prepare_job(job):
 
 
 def score_many(jobs):
-    """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word, no_grad}.
+    """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word, no_grad, uniform}.
     -> list of per-sentence log-probabilities [B], one per job.  All jobs advance layer by layer
     together, so their recurrences share persistent GRU launches; a `no_grad` job (an adversary
     that is only evaluated) is forward-only inside the shared launches."""
@@ -180,7 +181,8 @@ def score_many(jobs):
         gold = j["targets"][:, 1:].reshape(-1)
         with torch.set_grad_enabled(grad_on and not j.get("no_grad")):
             nll = ops.linear_ce(xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1), dec.out.weight, dec.out.bias,
-                                gold, dec.pad_id)
+                                gold, dec.pad_id,
+                                uniform_upstream=bool(j.get("uniform")) and not j.get("norm_by_word"))
             logp = -nll.view(B, T).sum(1)
             if j.get("norm_by_word"):
                 logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())

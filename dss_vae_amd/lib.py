@@ -39,7 +39,8 @@ _SIGNATURES = {
     "dssvae_device_cus": ([C.POINTER(C.c_int)], _I),
     "dssvae_gemm_f32": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _P], _I),
     "dssvae_gemm_f32_splitk": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _I, _P], _I),
-    "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P], _I),
+    "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P], _I),
+    "dssvae_softmax_grad_inplace": ([_P, _L, _P, _P, _I, _I, _P, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "dssvae_picked_logit": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _I, _P, _P], _I),
     "dssvae_linear_ce_dlogits": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P, _P], _I),

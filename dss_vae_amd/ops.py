@@ -267,7 +267,7 @@ def _pick_split(M, N):
     return s
 
 
-def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False):
+def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None):
     S = _pick_split(M, N)
     dev = xh.device
     pm = torch.empty(M, S, device=dev, dtype=torch.float32)
@@ -276,9 +276,10 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False):
     lib = L.load()
     with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S)):
         L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
-                                          L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.stream()),
+                                          L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
+                                          0 if logits is None else logits.stride(0), L.stream()),
                 "dssvae_linear_lse_fwd")
-    lse = torch.empty(M, device=dev, dtype=torch.float32)
+    lse = torch.empty(M, device=dev, dtype=torch.float32) if lse_out is None else lse_out
     arg = torch.empty(M, device=dev, dtype=torch.int64) if want_arg else None
     L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, L.ptr(lse), L.ptr(arg), L.stream()),
             "dssvae_lse_combine")
@@ -296,11 +297,29 @@ def _col_chunks(M, N):
     return nc
 
 
+def _row_chunks(M, ldd):
+    """rows per chunk so that a [rows, ldd] logits slab fits SLAB_BYTES (whole 128-row tiles, balanced)"""
+    mc_max = max(128, (SLAB_BYTES // (4 * ldd)) // 128 * 128)
+    n_chunks = (M + mc_max - 1) // mc_max
+    return ((M + n_chunks - 1) // n_chunks + 127) // 128 * 128
+
+
 class _LinearCEFn(Function):
-    """nll[m] = sum_t valid(m,t) * (lse[m] - logit[m, target[m,t]])  -- logits never materialised."""
+    """nll[m] = sum_t valid(m,t) * (lse[m] - logit[m, target[m,t]])  -- full logits never materialised.
+
+    Two training schedules:
+    * uniform=False (general): forward = fused projection + online LSE only; backward recomputes the
+      projection per chunk of vocabulary columns (4 GEMM passes per trainable head in total).
+    * uniform=True (the caller guarantees that every row receives the SAME upstream gradient, true for
+      every loss term of the DSS-VAE models: sums of per-token NLL scaled by constants): forward walks
+      row chunks; the LSE kernel also drops the chunk's logits into an Infinity-Cache-sized slab, which
+      is turned into dlogits in place and consumed by the dgrad / wgrad GEMMs right away.  The
+      gradients for upstream = 1 are kept and scaled in backward (dX per row, dW / db by the common
+      factor): 3 GEMM passes per trainable head, 2 per frozen one.  fp32 MFMA (157 TFLOP/s) makes the
+      recompute ~7x dearer than the slab round trip through the cache."""
 
     @staticmethod
-    def forward(ctx, xh, xe, W, b, target, ignore_index):
+    def forward(ctx, xh, xe, W, b, target, ignore_index, uniform):
         L.require_cuda(xh, W, target)
         xh, ldh = _rows(_f32(xh))
         Kh = xh.size(1)
@@ -309,28 +328,82 @@ class _LinearCEFn(Function):
             Ke = xe.size(1)
         else:
             lde, Ke = 0, 0
+        K = Kh + Ke
         W, ldw = _rows(_f32(W))
         M, N = xh.size(0), W.size(0)
-        assert W.size(1) == Kh + Ke
+        assert W.size(1) == K
         target = target.reshape(M, -1).contiguous()
         T = target.size(1)
-        lse, _ = _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N)
-        picked = torch.empty(M, T, device=xh.device, dtype=torch.float32)
-        L.check(L.load().dssvae_picked_logit(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b),
-                                             L.ptr(target), T, int(ignore_index), M, L.ptr(picked), L.stream()),
-                "dssvae_picked_logit")
+        dev = xh.device
+        lib = L.load()
         cnt = (target != ignore_index).sum(1).to(torch.float32)
-        ctx.save_for_backward(xh, xe, W, b, target, lse, cnt)
+        need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
+        need_xe = need_xe and xe is not None
+        need_b = need_b and b is not None
         ctx.ignore = int(ignore_index)
+        ctx.fused = bool(uniform) and (need_xh or need_xe or need_w or need_b)
+        if not ctx.fused:
+            lse, _ = _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N)
+        else:
+            ldd = (N + 3) // 4 * 4
+            mc = _row_chunks(M, ldd)
+            slab = torch.empty(min(mc, M), ldd, device=dev, dtype=torch.float32)
+            lse = torch.empty(M, device=dev, dtype=torch.float32)
+            need_x = need_xh or need_xe
+            dx = torch.empty(M, K, device=dev, dtype=torch.float32) if need_x else None
+            dW = torch.empty(N, K, device=dev, dtype=torch.float32) if need_w else None
+            db = torch.zeros(N, device=dev, dtype=torch.float32) if need_b else None
+            ones = torch.ones(M, T, device=dev, dtype=torch.float32)
+            xcat = None
+            if need_w:
+                xcat = xh if xe is None else torch.cat((xh, xe), dim=1)
+            for m0 in range(0, M, mc):
+                rows = min(mc, M - m0)
+                xh_c = xh[m0:m0 + rows]
+                xe_c = None if xe is None else xe[m0:m0 + rows]
+                dl = slab[:rows]
+                _lse(xh_c, ldh, Kh, xe_c, lde, Ke, W, ldw, b, rows, N, logits=dl, lse_out=lse[m0:m0 + rows])
+                L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, N,
+                                                        L.ptr(db), L.stream()), "dssvae_softmax_grad_inplace")
+                L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(ones[m0:]),
+                                              rows, 0, N, L.ptr(db), L.stream()), "dssvae_onehot_sub")
+                dlv = dl[:, :N]
+                if need_x:
+                    mm_nn(dlv, W, out=dx[m0:m0 + rows])
+                if need_w:
+                    mm_tn(dlv, xcat[m0:m0 + rows], out=dW, beta=0.0 if m0 == 0 else 1.0)
+            ctx.unit_grads = (dx, dW, db)
+            ctx.Kh = Kh
+        picked = torch.empty(M, T, device=dev, dtype=torch.float32)
+        L.check(lib.dssvae_picked_logit(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b),
+                                        L.ptr(target), T, ctx.ignore, M, L.ptr(picked), L.stream()),
+                "dssvae_picked_logit")
+        if not ctx.fused:
+            ctx.save_for_backward(xh, xe, W, b, target, lse, cnt)
         return cnt * lse - picked.sum(1)
 
     @staticmethod
     def backward(ctx, g):
-        """Per chunk of vocabulary columns: recompute dlogits into an Infinity-Cache-sized slab [M, nc]
-        (+ the bias gradient by column sums in the same kernel), subtract the one-hot part, then
-        dX += dL.W_chunk (dgrad, accumulating) and dW_chunk = dL^T.[xh|xe] (wgrad, written once)."""
-        xh, xe, W, b, target, lse, cnt = ctx.saved_tensors
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
+        if ctx.fused:
+            # every row has the same upstream gradient (the caller's contract): scale the unit gradients
+            dx, dW, db = ctx.unit_grads
+            ctx.unit_grads = None
+            c = g[:1]
+            dxh = dxe = None
+            if dx is not None:
+                dx.mul_(g.unsqueeze(1))
+                dxh = dx[:, :ctx.Kh] if need_xh else None
+                dxe = dx[:, ctx.Kh:] if (need_xe and dx.size(1) > ctx.Kh) else None
+            if dW is not None:
+                dW.mul_(c)
+            if db is not None:
+                db.mul_(c)
+            return dxh, dxe, dW, db, None, None, None
+        # general path: per chunk of vocabulary columns, recompute dlogits into an Infinity-Cache-sized
+        # slab [M, nc] (+ the bias gradient by column sums in the same kernel), subtract the one-hot part,
+        # then dX += dL.W_chunk (dgrad, accumulating) and dW_chunk = dL^T.[xh|xe] (wgrad, written once)
+        xh, xe, W, b, target, lse, cnt = ctx.saved_tensors
         xh, ldh = _rows(xh)
         Kh = xh.size(1)
         if xe is not None:
@@ -377,12 +450,13 @@ class _LinearCEFn(Function):
                 mm_tn(dlv, xcat, out=dW[n0:n1])
         dxh = dx[:, :Kh] if need_xh else None
         dxe = dx[:, Kh:] if need_xe else None
-        return dxh, dxe, dW, db, None, None
+        return dxh, dxe, dW, db, None, None, None
 
 
-def linear_ce(xh, xe, W, b, target, ignore_index=0):
-    """-> per-row summed NLL [M]; xe may be None; target [M] or [M,T]."""
-    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index)
+def linear_ce(xh, xe, W, b, target, ignore_index=0, uniform_upstream=False):
+    """-> per-row summed NLL [M]; xe may be None; target [M] or [M,T].  uniform_upstream=True: the caller
+    guarantees that every row's NLL receives the same upstream gradient (see _LinearCEFn)."""
+    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index, uniform_upstream)
 
 
 def linear_argmax(xh, xe, W, b):

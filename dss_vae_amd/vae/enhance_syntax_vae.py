@@ -13,6 +13,7 @@ class RNNPredictor(BridgeRNN):
     def forward(self, hidden, tgt_var, div_by_word=False):
         job = self.job(hidden, tgt_var)
         job["norm_by_word_len"] = div_by_word
+        job["uniform"] = not div_by_word
         return -_finish(job, score_many([job])[0]).sum()
 
     def detach(self):
@@ -32,7 +33,7 @@ def _finish(job, logp):
 
 class MLPPredictor(BridgeMLP):
     def forward(self, hidden, tgt_var, div_by_word=False):
-        loss = self.per_sentence(hidden, tgt_var)
+        loss = self.per_sentence(hidden, tgt_var, uniform=not div_by_word)
         if div_by_word:
             loss = loss.div(1e-9 + tgt_var.ne(self.pad_id).sum(-1).float())
         return loss.sum()

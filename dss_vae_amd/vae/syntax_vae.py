@@ -31,7 +31,9 @@ class BridgeRNN(nn.Module):
         self.pad_id = ent.pad_id
 
     def job(self, hidden, tgt_var):
-        return dict(dec=self.decoder, inputs=tgt_var, targets=tgt_var, h0=self.bridger.forward(input_tensor=hidden))
+        """scoring job; `uniform`: the models only ever sum per-sentence NLLs with one common weight"""
+        return dict(dec=self.decoder, inputs=tgt_var, targets=tgt_var, h0=self.bridger.forward(input_tensor=hidden),
+                    uniform=True)
 
     def forward(self, hidden, tgt_var):
         return -score_many([self.job(hidden, tgt_var)])[0]
@@ -54,13 +56,13 @@ class BridgeMLP(nn.Module):
         self.pad_id = vocab.src.pad_id
         self.p = float(args.dec_rd)
 
-    def per_sentence(self, hidden, tgt_var):
+    def per_sentence(self, hidden, tgt_var, uniform=True):
         B = tgt_var.size(0)
         feat = self.bridger.forward(input_tensor=hidden).permute(1, 0, 2).contiguous().view(B, -1)
         if self.training and self.p > 0.0:
             feat = feat * ops.dropout_mask(tuple(feat.shape), self.p, GLOBAL_SEEDS.next(), feat.device)
         lin = self.scorer[1]
-        return ops.linear_ce(feat, None, lin.weight, lin.bias, tgt_var, self.pad_id)
+        return ops.linear_ce(feat, None, lin.weight, lin.bias, tgt_var, self.pad_id, uniform_upstream=uniform)
 
     def forward(self, hidden, tgt_var):
         return self.per_sentence(hidden, tgt_var).sum()
@@ -153,7 +155,7 @@ class TwoEncoderVAE(BaseVAE):
         if self.training and self.args.tgt_wd:
             inputs = self._word_dropout(tgt_var, "rand_tgt")
         return dict(dec=self.decoder, inputs=inputs, targets=tgt_var,
-                    h0=self.bridger.forward(ret["decode_init"]))
+                    h0=self.bridger.forward(ret["decode_init"]), uniform=True)
 
     def _kl_terms(self, ret, step):
         a = self.args

@@ -62,7 +62,7 @@ class VanillaVAE(BaseVAE):
         inputs = tgt_var
         if self.training and self.args.tgt_wd > 0.0:
             inputs = self._word_dropout(tgt_var, "rand_tgt")
-        nll = -torch.sum(self.decoder.score_inputs(inputs, tgt_var, h0))
+        nll = -torch.sum(self.decoder.score_inputs(inputs, tgt_var, h0, uniform=True))
         return {"mean": ret["mean"], "logv": ret["logv"], "z": ret["latent"], "kl": ret["kl"], "nll_loss": nll,
                 "batch_size": len(batch)}
 

@@ -60,6 +60,9 @@ int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64
  * dssvae_linear_lse_fwd writes, per row m and column split s (n_split of them), the running
  * max and sum(exp(logit - max)) of that split into part_max/part_sum [M, n_split]; with
  * want_argmax it also writes the split's best column into part_arg [M, n_split].
+ * logits (may be NULL): side output, the logits of these M rows into a caller slab [M, ldl]
+ * (the training path passes a row chunk sized to stay in the Infinity Cache and turns it into
+ * dlogits in place with dssvae_softmax_grad_inplace, so backward never recomputes the projection).
  * Replaces: RNNDecoder.forward_step's `self.out(cat(output, embedded))` + F.log_softmax
  * (decoder/rnn_decoder.py:70-73,94) and the scorer Linear+LogSoftmax of the bag-of-words heads
  * (vae/enhance_syntax_vae.py:607-615).  Xe may be NULL (Ke = 0).
@@ -67,7 +70,13 @@ int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64
 int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
                           const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
                           float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
-                          void* stream);
+                          float* logits, int64_t ldl, void* stream);
+
+/* X[m,n] <- coef[m] * exp(X[m,n] - lse[m]) in place on a logits slab [M, ldx] (ldx % 4 == 0);
+ * colsum (may be NULL) [N] += column sums of the result (atomics: zero it first).  The softmax part
+ * of autograd(log_softmax + gather) (decoder/rnn_decoder.py:94-102). */
+int dssvae_softmax_grad_inplace(float* X, int64_t ldx, const float* lse, const float* coef, int M, int N,
+                                float* colsum, void* stream);
 
 /* lse[m] = log sum_n exp(logit[m,n]) from the split partials; argmax[m] (may be NULL). */
 int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg,

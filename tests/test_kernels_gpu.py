@@ -82,6 +82,40 @@ def test_linear_ce_forward_backward(M, Kh, Ke, N, T):
             close(a.grad, r.grad, rtol=2e-4, atol=2e-5, what=name)
 
 
+@pytest.mark.parametrize("M,Kh,Ke,N,T,frozen", [(7, 8, 4, 11, 1, False), (300, 120, 20, 2000, 1, False),
+                                                (37, 16, 0, 515, 9, False), (256, 600, 0, 3001, 32, True),
+                                                (130, 30, 18, 777, 1, False), (520, 64, 32, 1300, 1, True)])
+def test_linear_ce_uniform_upstream_schedule(M, Kh, Ke, N, T, frozen, monkeypatch):
+    """uniform_upstream=True: logits of a row chunk go to a slab in the forward pass, gradients for
+    upstream 1 are produced there and scaled in backward; same numbers as the reference when every
+    row gets the same upstream gradient.  `frozen`: projection weights without grad (an adversary
+    head after the freeze), several row chunks forced by a small slab."""
+    from dss_vae_amd import ops
+    if frozen:
+        monkeypatch.setattr(ops, "SLAB_BYTES", 128 * ((N + 3) // 4 * 4) * 4)
+    g = torch.Generator().manual_seed(M + N)
+    xh, W, b = rnd(M, Kh, seed=1), rnd(N, Kh + Ke, seed=2, scale=0.3), rnd(N, seed=3, scale=0.1)
+    xe = rnd(M, Ke, seed=4) if Ke else None
+    tgt = torch.randint(0, N, (M, T), generator=g)
+    tgt[torch.rand(M, T, generator=g) < 0.3] = 0
+    tgt = tgt.squeeze(1) if T == 1 else tgt
+    scale = 0.37
+    leaves = [t.clone().double().requires_grad_(True) if t is not None else None for t in (xh, xe, W, b)]
+    ref = ce_reference(*leaves, tgt, 0)
+    (ref.sum() * scale).backward()
+    dl = [t.clone().to(DEV).requires_grad_(True) if t is not None else None for t in (xh, xe, W, b)]
+    if frozen:
+        dl[2].requires_grad_(False), dl[3].requires_grad_(False)
+    out = ops.linear_ce(dl[0], dl[1], dl[2], dl[3], tgt.to(DEV), 0, uniform_upstream=True)
+    close(out, ref, rtol=1e-5, atol=1e-4, what="nll")
+    (out.sum() * scale).backward()
+    for name, a, r in zip(("dxh", "dxe", "dW", "db"), dl, leaves):
+        if a is not None and a.requires_grad:
+            close(a.grad, r.grad, rtol=2e-4, atol=2e-5, what=name)
+        elif a is not None:
+            assert a.grad is None
+
+
 def test_linear_ce_small_slab_chunks(monkeypatch):
     """backward must give the same result when the dlogits slab forces many row chunks."""
     from dss_vae_amd import ops
