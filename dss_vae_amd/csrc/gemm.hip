@@ -256,12 +256,55 @@ __device__ __forceinline__ int acc_col(int nt) {
     return wc * 32 * WN + nt * 32 + (lane & 31);
 }
 
+// Accumulator tile -> global through LDS: lanes write their elements (one row segment of 32 consecutive
+// floats per lane-half: conflict-free ds_write_b32), the tile is read back row-major and leaves as
+// 16-byte stores of full 128-/256-/512-B row segments (4x fewer store instructions than the
+// accumulator's natural one-dword-per-lane pattern, which is store-issue bound).  Needs ldc % 4 == 0,
+// C 16-B aligned, N % 4 == 0 (cvec); otherwise dword stores from the same image.  beta != 0: C is read.
+// Callers must have passed a barrier since the last LDS use; ends with a barrier.
+template <int WM, int WN>
+__device__ __forceinline__ void tile_to_global(const f32x16 (&acc)[WM][WN], float* lds, float* __restrict__ C,
+                                               int64_t ldc, int m0, int n0, int M, int N, float beta, bool cvec) {
+    constexpr int BM = 64 * WM, BN = 64 * WN, LDT = BN + 4;
+    static_assert(BM * LDT <= lds_floats<false, false, WM, WN>() && BM * LDT <= lds_floats<true, true, WM, WN>(),
+                  "output tile image must fit in the operand buffers");
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) lds[acc_row<WM>(mt, r) * LDT + acc_col<WN>(nt)] = acc[mt][nt][r];
+    __syncthreads();
+    constexpr int TPR = BN / 4, RPP = NTHREADS / TPR;
+    const int col = 4 * (threadIdx.x % TPR), n = n0 + col;
+#pragma unroll 4
+    for (int i = 0; i < BM / RPP; ++i) {
+        const int row = threadIdx.x / TPR + RPP * i, m = m0 + row;
+        if (m >= M || n >= N) continue;
+        float4 v = *reinterpret_cast<const float4*>(lds + row * LDT + col);
+        float* c = C + (int64_t)m * ldc + n;
+        if (cvec) {
+            if (beta != 0.f) {
+                const float4 o = *reinterpret_cast<const float4*>(c);
+                v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+            }
+            *reinterpret_cast<float4*>(c) = v;
+        } else {
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n + j < N) c[j] = beta != 0.f ? e[j] + beta * c[j] : e[j];
+        }
+    }
+    __syncthreads();
+}
+
 // ---- STORE ---------------------------------------------------------------------------------------
 template <bool TA, bool TB, bool VEC, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
                                                                const float* __restrict__ bias, int M, int N, int K,
                                                                float alpha, float beta, int tiles_n, int ntiles,
-                                                               int ksplit, int kt_per_split) {
+                                                               int ksplit, int kt_per_split, int cvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 64 * WM, BN = 64 * WN;
     const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
@@ -272,28 +315,33 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
     if (kt0 >= kt1) return;
     f32x16 acc[WM][WN];
     tile_mainloop<TA, TB, VEC, WM, WN>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
+    if (ksplit > 1) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int n = n0 + acc_col<WN>(nt);
+            if (n >= N) continue;
+            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + acc_row<WM>(mt, r);
+                    // C was zeroed (beta = 0) or holds the addend (beta = 1)
+                    if (m < M) unsafeAtomicAdd(C + (int64_t)m * ldc + n, alpha * acc[mt][nt][r] + bv);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) {
         const int n = n0 + acc_col<WN>(nt);
-        if (n >= N) continue;
-        const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+        const float bv = (bias && n < N) ? bias[n] : 0.f;
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + acc_row<WM>(mt, r);
-                if (m < M) {
-                    float v = alpha * acc[mt][nt][r] + bv;
-                    float* c = C + (int64_t)m * ldc + n;
-                    if (ksplit > 1) {
-                        unsafeAtomicAdd(c, v);  // C was zeroed (beta = 0) or holds the addend (beta = 1)
-                    } else {
-                        if (beta != 0.f) v += beta * *c;
-                        *c = v;
-                    }
-                }
-            }
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = alpha * acc[mt][nt][r] + bv;
     }
+    tile_to_global<WM, WN>(acc, lds, C, ldc, m0, n0, M, N, beta, cvec != 0);
 }
 
 // ---- LSE (optionally with argmax) ----------------------------------------------------------------
@@ -303,7 +351,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
                                                                int tiles_n, float* __restrict__ part_max,
                                                                float* __restrict__ part_sum,
                                                                int64_t* __restrict__ part_arg,
-                                                               float* __restrict__ logits, int64_t ldl) {
+                                                               float* __restrict__ logits, int64_t ldl, int lvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128;
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
@@ -331,14 +379,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
             for (int r = 0; r < 16; ++r) {
                 const float x0 = ok0 ? acc[mt][0][r] + b0 : NEG_BIG;
                 const float x1 = ok1 ? acc[mt][1][r] + b1 : NEG_BIG;
-                if (STORE) {  // side output: the logits of this row chunk into the cache-resident slab
-                    const int m = m0 + acc_row<2>(mt, r);
-                    if (m < M) {
-                        float* row = logits + (int64_t)m * ldl;
-                        if (ok0) row[c0] = x0;
-                        if (ok1) row[c1] = x1;
-                    }
-                }
+                if (STORE) { acc[mt][0][r] = x0; acc[mt][1][r] = x1; }
                 const float mo = rm[mt][r];
                 const float mn = fmaxf(mo, fmaxf(x0, x1));
                 rs[mt][r] = rs[mt][r] * __expf(mo - mn) + __expf(x0 - mn) + __expf(x1 - mn);
@@ -348,6 +389,8 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
                 }
                 rm[mt][r] = mn;
             }
+        // side output: the logits of this row chunk into the cache-resident slab
+        if (STORE) tile_to_global<2, 2>(acc, lds, logits, ldl, m0, n0, M, N, 0.f, lvec != 0);
     }
     // reduce over the 32 lanes that hold different columns of the same rows
 #pragma unroll
@@ -420,7 +463,8 @@ __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, 
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ coef, int M, int N, int K,
                                                                    float* __restrict__ dL, int64_t ldd,
-                                                                   float* __restrict__ colsum, int tiles_n, int ntiles) {
+                                                                   float* __restrict__ colsum, int tiles_n, int ntiles,
+                                                                   int dvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128;
     const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -436,12 +480,14 @@ __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + acc_row<2>(mt, r);
-            if (m >= M) continue;
-            const float l = lse[m], c = coef[m];
-            float* row = dL + (int64_t)m * ldd;
-            if (ok0) { const float v = c * __expf(acc[mt][0][r] + b0 - l); row[c0] = v; s0 += v; }
-            if (ok1) { const float v = c * __expf(acc[mt][1][r] + b1 - l); row[c1] = v; s1 += v; }
+            const bool okm = m < M;
+            const float l = okm ? lse[m] : 0.f, c = okm ? coef[m] : 0.f;
+            const float v0 = (okm && ok0) ? c * __expf(acc[mt][0][r] + b0 - l) : 0.f;
+            const float v1 = (okm && ok1) ? c * __expf(acc[mt][1][r] + b1 - l) : 0.f;
+            acc[mt][0][r] = v0; acc[mt][1][r] = v1;
+            s0 += v0; s1 += v1;
         }
+    tile_to_global<2, 2>(acc, lds, dL, ldd, m0, n0, M, N, 0.f, dvec != 0);
     if (colsum) {
         s0 += __shfl_xor(s0, 32, 64);
         s1 += __shfl_xor(s1, 32, 64);
@@ -585,8 +631,9 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
     auto kern = gemm_store_kernel<TA, TB, VEC, WM, WN>;
     allow_lds(kern, lds_bytes);
+    const int cvec = aligned16(C) && (ldc % 4) == 0 && (N % 4) == 0;
     hipLaunchKernelGGL(kern, dim3(ntiles * ksplit), dim3(NTHREADS), lds_bytes, s, a, b, C, ldc, bias, M, N, K, alpha,
-                       beta, tiles_n, ntiles, ksplit, ktps);
+                       beta, tiles_n, ntiles, ksplit, ktps, cvec);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -654,12 +701,13 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
     const int tps = (tiles_n + n_split - 1) / n_split;
     hipStream_t s = (hipStream_t)stream;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
+    const int lvec = logits && aligned16(logits) && (ldl % 4) == 0 && (N % 4) == 0;
 #define GO(ARG, VEC, ST)                                                                                          \
     do {                                                                                                          \
         allow_lds(linear_lse_kernel<ARG, VEC, ST>, lds_bytes);                                                    \
         hipLaunchKernelGGL((linear_lse_kernel<ARG, VEC, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes, \
                            s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg,     \
-                           logits, ldl);                                                                          \
+                           logits, ldl, lvec);                                                                    \
     } while (0)
     if (logits) { if (vec) GO(false, true, true); else GO(false, false, true); }
     else if (want_argmax) { if (vec) GO(true, true, false); else GO(true, false, false); }
@@ -702,14 +750,15 @@ extern "C" int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, co
     vec = vec && vec_ok(W, ldw);
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, ntiles = tiles_m * tiles_n;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
+    const int dvec = aligned16(dL) && (ldd % 4) == 0 && (N % 4) == 0;
     if (vec) {
         allow_lds(linear_dlogits_kernel<true>, lds_bytes);
         hipLaunchKernelGGL(linear_dlogits_kernel<true>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
-                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles);
+                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles, dvec);
     } else {
         allow_lds(linear_dlogits_kernel<false>, lds_bytes);
         hipLaunchKernelGGL(linear_dlogits_kernel<false>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
-                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles);
+                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles, dvec);
     }
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;

@@ -286,7 +286,8 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None,
     return lse, arg
 
 
-SLAB_BYTES = 128 << 20  # column-chunk slab of dlogits: sized to stay inside the 256 MiB Infinity Cache
+import os as _os
+SLAB_BYTES = int(_os.environ.get("DSSVAE_SLAB_MB", "128")) << 20  # dlogits slab: sized to stay inside the 256 MiB Infinity Cache
 
 
 def _col_chunks(M, N):
