@@ -49,6 +49,8 @@ def parse():
     ap.add_argument("--tree-len", type=int, default=90)
     ap.add_argument("--variable-lengths", action="store_true")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[3]: hidden 1024, latent 256")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product); gloo only to rehearse the N>1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=32)
@@ -104,10 +106,14 @@ def main():
         raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
                          "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if a.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group("gloo")
 
     from dss_vae_amd import ops, synthetic
     from dss_vae_amd.models import MODEL_CLS

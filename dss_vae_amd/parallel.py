@@ -20,23 +20,37 @@ def shard_examples(examples, rank, world):
     return part
 
 
+def world_size(group=None):
+    return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+
+
 class GradBuckets(object):
     """Bucketed, overlapped gradient averaging over one flat gradient buffer.
 
     params[i] owns flat[offsets[i] : offsets[i] + params[i].numel()].  Buckets are contiguous ranges of
-    the flat buffer of about `bucket_elems` elements, walked from the END of the buffer (gradients
+    the flat buffer of about `bucket_elems` elements, numbered from the END of the buffer (gradients
     arrive roughly in reverse registration order).  `mark_ready(i)` is called from a post-accumulate
-    hook of parameter i; when every parameter of a bucket that can receive a gradient this step has
-    reported, the bucket is all-reduced asynchronously.  `finish()` reduces whatever has not been sent
-    (parameters that got no gradient still take part: their slice holds zeros on every rank) and waits.
+    hook of parameter i.
+
+    Which parameters receive a gradient is a property of the autograd graph of the step, not of
+    requires_grad at any one moment (EnhanceSyntaxVAE freezes its adversaries half-way through forward),
+    so it is LEARNED: the first step of a kind (`tag`) reduces everything at `finish()` and records
+    the set of parameters whose hooks fired; the next step of that kind expects the same set and
+    all-reduces a bucket asynchronously as soon as all of its expected parameters have reported -- but
+    only once every lower-numbered bucket has been sent, so all ranks issue their collectives in ONE
+    fixed order whatever order autograd fires the hooks in (RCCL requires identical issue order on
+    every rank; the fired sets are identical on all ranks because the graphs are).  A gradient that
+    arrives for a bucket that is already on the wire cannot be repaired and raises.  `finish()` sends
+    whatever has not been sent (parameters that got no gradient still take part: their slice holds
+    zeros on every rank) and makes the averaged gradients visible to the current stream.
     """
 
-    def __init__(self, flat_grad, params, offsets, bucket_elems, group=None):
+    def __init__(self, flat_grad, params, offsets, bucket_elems, group=None, overlap=True):
         self.flat, self.params, self.offsets, self.group = flat_grad, params, offsets, group
-        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.backend = dist.get_backend(group) if self.world > 1 else None
-        self.cuda = flat_grad.is_cuda
-        self.comm = torch.cuda.Stream(device=flat_grad.device) if (self.cuda and self.world > 1) else None
+        self.world = world_size(group)
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
+        self.overlap = overlap
+        self.comm = torch.cuda.Stream(device=flat_grad.device) if flat_grad.is_cuda else None
         # bucket boundaries: whole parameters, contiguous, from the end
         self.buckets = []  # (lo, hi, [param indices])
         hi, cur, lo = flat_grad.numel(), [], flat_grad.numel()
@@ -49,24 +63,27 @@ class GradBuckets(object):
         if cur:
             self.buckets.append((lo, hi, cur))
         if self.buckets:
-            lo0, hi0, idx0 = self.buckets[-1]
+            _, hi0, idx0 = self.buckets[-1]
             self.buckets[-1] = (0, hi0, idx0)  # alignment padding in front of the first parameter
         self.bucket_of = {}
         for b, (_, _, idx) in enumerate(self.buckets):
             for i in idx:
                 self.bucket_of[i] = b
+        self.expected = {}  # tag -> frozenset of parameter indices that fired in the last step of that kind
+        self.sent_early = 0  # buckets sent from hooks in the last step (observability / tests)
         self.reset()
 
-    def reset(self):
-        self.pending = [sum(1 for i in idx if self.params[i].requires_grad) for _, _, idx in self.buckets]
-        self.sent = [False] * len(self.buckets)
+    def reset(self, tag="main"):
+        self.tag = tag
+        self.expect = self.expected.get(tag) if self.overlap else None
+        self.fired = set()
+        if self.expect is not None:
+            self.pending = [sum(1 for i in idx if i in self.expect) for _, _, idx in self.buckets]
+        self.next = 0      # buckets [0, next) have been sent
         self.works = []
+        self.sent_early = 0
 
-    def _launch(self, b):
-        if self.sent[b] or self.world == 1:
-            self.sent[b] = True
-            return
-        self.sent[b] = True
+    def _send(self, b):
         lo, hi, _ = self.buckets[b]
         chunk = self.flat[lo:hi]
         if self.comm is not None:
@@ -77,29 +94,49 @@ class GradBuckets(object):
             self._reduce(chunk)
 
     def _reduce(self, chunk):
-        if self.backend == "nccl":
+        if self.backend == "nccl":  # RCCL: the product path
             self.works.append((dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        elif chunk.is_cuda:
+            # gloo with device buffers is only a rehearsal of the N>1 schedule on a one-GPU box: staged
+            # through the host synchronously (gloo's own asynchronous device path stalls under HIP
+            # when many works are outstanding)
+            host = chunk.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            chunk.copy_(host.div_(self.world))
         else:
             self.works.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
     def mark_ready(self, i):
-        if self.world == 1:
+        self.fired.add(i)
+        if self.expect is None:
             return
         b = self.bucket_of[i]
-        self.pending[b] -= 1
-        if self.pending[b] == 0:
-            self._launch(b)
+        if b < self.next:
+            raise RuntimeError(
+                "gradient of parameter %d arrived after its bucket was all-reduced: the autograd graph of this "
+                "step (tag %r) differs from the previous one; set DSSVAE_DP_OVERLAP=0 or give the steps "
+                "different tags" % (i, self.tag))
+        if i in self.expect:
+            self.pending[b] -= 1
+            while self.next < len(self.buckets) and self.pending[self.next] <= 0:
+                self._send(self.next)
+                self.next += 1
+                self.sent_early += 1
 
     def finish(self):
         """all buckets reduced and visible to the current stream"""
-        if self.world == 1:
-            return
-        for b in range(len(self.buckets)):
-            self._launch(b)
+        while self.next < len(self.buckets):
+            self._send(self.next)
+            self.next += 1
         for work, chunk in self.works:
             work.wait()
             if chunk is not None:
-                chunk.div_(self.world)
+                if self.comm is not None:
+                    with torch.cuda.stream(self.comm):
+                        chunk.div_(self.world)
+                else:
+                    chunk.div_(self.world)
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
         self.works = []
+        self.expected[self.tag] = frozenset(self.fired)

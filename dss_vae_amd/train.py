@@ -10,10 +10,12 @@ into ONE flat gradient buffer, so that
     (HBM-bound: 16 B read + 12 B written per parameter), with the clip coefficient read on device
     (no host sync in the step).
 """
+import os
+
 import torch
-import torch.distributed as dist
 
 from . import ops
+from .parallel import GradBuckets, world_size
 
 
 def build_model_params_(model, seed=None, bound=0.08):
@@ -31,7 +33,7 @@ class FlatAdam(object):
     """Adam + clip_grad_norm_ over flat parameter / gradient buffers, optionally data-parallel."""
 
     def __init__(self, model, lr=0.0005, betas=(0.9, 0.995), eps=1e-8, clip_grad=5.0, bucket_mb=64,
-                 process_group=None):
+                 process_group=None, data_parallel=True):
         params = [p for p in model.parameters()]
         assert params and all(p.is_cuda and p.dtype == torch.float32 for p in params), \
             "FlatAdam needs the model on the MI355X (model.cuda()) in fp32"
@@ -52,18 +54,32 @@ class FlatAdam(object):
         self.params, self.lr, self.betas, self.eps, self.clip = params, lr, betas, eps, clip_grad
         self.t = 0
         self.sumsq = torch.zeros(1, device=dev)
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.bucket = max(1, int(bucket_mb * (1 << 20) // 4))
-        self.comm = torch.cuda.Stream(device=dev) if self.world > 1 else None
+        self.world = world_size(process_group) if data_parallel else 1
+        self.buckets = None
+        force = os.environ.get("DSSVAE_DP_FORCE", "0") == "1" and data_parallel and world_size(process_group) == 1 \
+            and torch.distributed.is_initialized()
+        if self.world > 1 or force:  # force: rehearse the whole DP schedule on a 1-rank group
+            offsets, o = [], 0
+            for n in sizes:
+                offsets.append(o)
+                o += n
+            overlap = os.environ.get("DSSVAE_DP_OVERLAP", "1") != "0"
+            self.buckets = GradBuckets(self.grad, params, offsets, max(1, int(bucket_mb * (1 << 20) // 4)),
+                                       group=process_group, overlap=overlap)
+            for i, p in enumerate(params):
+                p.register_post_accumulate_grad_hook(lambda _p, i=i: self.buckets.mark_ready(i))
 
-    def zero_grad(self):
+    def zero_grad(self, tag="main"):
+        """tag: kind of step that follows (steps of one kind share an autograd graph shape; the
+        data-parallel bucket schedule is learned per kind)."""
         self.grad.zero_()
         for p in self.params:  # autograd may have replaced a view (e.g. after requires_grad toggling)
             if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr() or \
                     p.grad.data_ptr() >= self.grad.data_ptr() + self.grad.numel() * 4:
                 self._rebind()
                 break
+        if self.buckets is not None:
+            self.buckets.reset(tag)
 
     def _rebind(self):
         off = 0
@@ -72,23 +88,9 @@ class FlatAdam(object):
             off += (p.numel() + 3) // 4 * 4
 
     def all_reduce_grads(self):
-        """bucketed gradient averaging over RCCL (xGMI) on a side stream."""
-        if self.world == 1:
-            return
-        self.comm.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(self.comm):
-            works = []
-            for lo in range(0, self.grad.numel(), self.bucket):
-                chunk = self.grad[lo:lo + self.bucket]
-                if dist.get_backend(self.group) == "nccl":
-                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
-                else:
-                    works.append(dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
-            for w in works:
-                w.wait()
-            if dist.get_backend(self.group) != "nccl":
-                self.grad.div_(self.world)
-        torch.cuda.current_stream().wait_stream(self.comm)
+        """gradient average over RCCL (xGMI): buckets not yet sent by the backward hooks go now."""
+        if self.buckets is not None:
+            self.buckets.finish()
 
     def step(self):
         self.all_reduce_grads()
