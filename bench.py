@@ -36,6 +36,18 @@ KERNEL_BOUND = {
 }
 
 
+def pmc_traffic():
+    """HBM-side bytes per launch per kernel from the rocprofv3 PMC passes of this same command
+    (FETCH_SIZE and WRITE_SIZE in separate runs, corrected as MI355X_MICROARCH.md prescribes:
+    (2*FETCH_SIZE + WRITE_SIZE) KiB; tools/pmc_summary.py), newest profiles/*pmc_traffic.json."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")))
+    if not files:
+        return {}, None
+    with open(files[-1]) as fh:
+        return json.load(fh), os.path.relpath(files[-1], ROOT)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -179,6 +191,9 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
+            default_cfg = (a.model, a.batch, a.vocab, a.tree_vocab, a.src_len, a.tree_len, a.variable_lengths,
+                           a.stress) == ("SyntaxVAE2", 256, 30000, 300, 30, 90, False, False)
+            traffic, traffic_src = pmc_traffic() if default_cfg else ({}, None)
             kernels = []
             for name, d in summ.items():
                 bound = KERNEL_BOUND.get(name, "hbm")
@@ -189,13 +204,18 @@ def main():
                     ach = d["bytes"] / (d["total_ms"] * 1e-3) / 1e9
                     peak, unit = PEAK_HBM_GBS, "GB/s"
                 kernels.append({"kernel": name, "bound": bound, "achieved": ach, "peak": peak, "unit": unit,
-                                "frac": ach / peak, "traffic": None, "launches_per_step": d["launches"] / a.steps,
+                                "frac": ach / peak,
+                                "traffic": traffic.get(name, {}).get("hbm_bytes_per_launch"),
+                                "algorithmic_per_launch": (d["flops"] if bound == "mfma" else d["bytes"]) / d["launches"],
+                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                                "launches_per_step": d["launches"] / a.steps,
                                 "avg_launch_ms": d["avg_ms"], "ms_per_step": d["total_ms"] / a.steps})
             kernels.sort(key=lambda k: -k["ms_per_step"])
             if kernels:
                 out["roofline"] = kernels[0]
                 out["kernels"] = kernels[1:]
                 out["timed_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
+                out["traffic_source"] = traffic_src
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
