@@ -61,6 +61,11 @@ def parse():
     ap.add_argument("--tree-len", type=int, default=90)
     ap.add_argument("--variable-lengths", action="store_true")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[3]: hidden 1024, latent 256")
+    ap.add_argument("--mode", default="train", choices=["train", "generate"],
+                    help="train = the headline metric; generate = BASELINE configs[4] (prior sampling + syntax "
+                         "transfer greedy decode), a secondary line")
+    ap.add_argument("--gen-sentences", type=int, default=10000)
+    ap.add_argument("--gen-batch", type=int, default=50, help="eval_bs (reference default 50)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the product); gloo only to rehearse the N>1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -104,6 +109,51 @@ def cpu_baseline(a, margs_dict):
             "s_per_step": med}
 
 
+def generate_bench(a, model, vocab, margs, rank, world):
+    """BASELINE configs[4]: decoder-only generation.  (1) prior sampling: `generating(n, eval_bs)`
+    (base_vae.py:69-85), always max_len = 35 greedy steps, tokens -> words on the host as the reference
+    does; (2) syntax transfer: `eval_adv(sem_in, syn_ref)` (enhance_syntax_vae.py:485-497) = two encodes,
+    one sentence decode and two 100-step tree decodes per pair batch.  Replicas only: each rank
+    generates its share, no collective."""
+    import torch
+    from dss_vae_amd import synthetic
+    model.eval()
+    n, bs = a.gen_sentences // world, a.gen_batch
+    torch.manual_seed(7 + rank)
+    out = {}
+    with torch.no_grad():
+        model.generating(bs, bs)  # warm-up
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = model.generating(n, bs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["prior_sampling"] = {"sentences": len(res), "seconds": dt, "sentences_per_s": len(res) / dt}
+        if a.model == "SyntaxVAE2":
+            exs = synthetic.examples(bs, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len, fixed=False,
+                                     seed=99 + rank)
+            ref = synthetic.examples(bs, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len, fixed=False,
+                                     seed=199 + rank)
+            model.eval_adv(exs, ref)
+            torch.cuda.synchronize()
+            reps = max(1, n // bs)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model.eval_adv(exs, ref)
+            torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t0
+            out["syntax_transfer"] = {"pairs": reps * bs, "seconds": dt2, "pairs_per_s": reps * bs / dt2}
+    line = {"metric": "generation sentences/sec (greedy, prior sampling) DSS-VAE", "value": world * len(res) / dt,
+            "unit": "sentences/s", "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[4]: %s decoder-only generation, %d prior samples per GPU at "
+                                   "eval_bs %d, max_len %d, vocab %d" % (a.model, n, bs, margs.src_max_time_step,
+                                                                         a.vocab)}}
+    line.update(out)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
+
 def main():
     a = parse()
     import torch
@@ -143,6 +193,8 @@ def main():
     model.cuda().train()
     n_params = sum(p.numel() for p in model.parameters())
     opt = FlatAdam(model, lr=0.0005, betas=(0.9, 0.995), clip_grad=5.0)
+    if a.mode == "generate":
+        return generate_bench(a, model, vocab, margs, rank, world)
     exs = synthetic.examples(a.batch, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len,
                              fixed=not a.variable_lengths, seed=1234 + rank)
     batch = DeviceBatch(exs, vocab)

@@ -1,0 +1,99 @@
+// Greedy generation loop (decoder/rnn_decoder.py:160-168,193-199) as ONE native call: for max_len steps,
+// embedding rows of the previous tokens -> per layer two small MFMA GEMMs (x W_ih^T + b_ih, h W_hh^T + b_hh)
+// + the fused GRU cell -> output projection fused with a running arg-max over vocabulary splits (no
+// softmax is needed for an arg-max, no [B,V] row is written) -> tokens[t].  The host loop only enqueues
+// kernels on the caller's stream: no allocation, no synchronisation, no device->host traffic (the
+// reference does a topk + .cpu() per step), so the whole decode is also capturable in a HIP graph.
+#include "common.h"
+
+namespace {
+struct Ws {
+    float* x;        // [B,E]   embedding rows of the current tokens
+    float* gi;       // [B,3H]
+    float* gh;       // [B,3H]
+    float* pmax;     // [B,S]
+    float* psum;     // [B,S]
+    int64_t* parg;   // [B,S]
+    int64_t* tok;    // [B]
+    float* h;        // [L][B,H]
+    size_t bytes;
+};
+
+inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+Ws carve(void* base, int B, int E, int H, int L, int S) {
+    Ws w;
+    char* p = static_cast<char*>(base);
+    size_t off = 0;
+    auto take = [&](size_t n) { size_t o = off; off += up256(n); return p ? p + o : nullptr; };
+    w.x = reinterpret_cast<float*>(take((size_t)B * E * 4));
+    w.gi = reinterpret_cast<float*>(take((size_t)B * 3 * H * 4));
+    w.gh = reinterpret_cast<float*>(take((size_t)B * 3 * H * 4));
+    w.pmax = reinterpret_cast<float*>(take((size_t)B * S * 4));
+    w.psum = reinterpret_cast<float*>(take((size_t)B * S * 4));
+    w.parg = reinterpret_cast<int64_t*>(take((size_t)B * S * 8));
+    w.tok = reinterpret_cast<int64_t*>(take((size_t)B * 8));
+    w.h = reinterpret_cast<float*>(take((size_t)L * B * H * 4));
+    w.bytes = off;
+    return w;
+}
+
+__global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+}  // namespace
+
+extern "C" int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split) {
+    if (B <= 0 || E <= 0 || H <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
+        return DSSVAE_EINVAL;
+    return (int64_t)carve(nullptr, B, E, H, n_layers, n_split).bytes;
+}
+
+extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* h0, int B, int max_len,
+                                    int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    if (!p || !h0 || !tokens || !workspace || B <= 0 || max_len <= 0 || n_split <= 0) return DSSVAE_EINVAL;
+    const int E = p->E, H = p->H, L = p->n_layers, V = p->V;
+    if (E <= 0 || H <= 0 || V <= 0 || L <= 0 || L > DSSVAE_DECODE_MAX_LAYERS || !p->embedding || !p->w_out ||
+        p->ld_embedding < E || p->ld_out < H + E || sos_id < 0 || sos_id >= p->n_embeddings)
+        return DSSVAE_EINVAL;
+    for (int l = 0; l < L; ++l)
+        if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return DSSVAE_EINVAL;
+    if (!aligned16(workspace)) return DSSVAE_EINVAL;
+    const Ws w = carve(workspace, B, E, H, L, n_split);
+    if ((int64_t)w.bytes > workspace_bytes) return DSSVAE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    hipError_t e = hipMemcpyAsync(w.h, h0, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.tok, sos_id, B);
+    DSSVAE_CHECK_LAUNCH();
+    int rc;
+#define TRY(call) do { rc = (call); if (rc != DSSVAE_OK) return rc; } while (0)
+    for (int t = 0; t < max_len; ++t) {
+        TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, w.tok, B, E, nullptr, w.x, E, stream));
+        const float* in = w.x;
+        int in_dim = E;
+        for (int l = 0; l < L; ++l) {
+            float* hl = w.h + (size_t)l * B * H;
+            TRY(dssvae_gemm_f32(in, in_dim, 0, nullptr, p->w_ih[l], in_dim, 0, w.gi, 3 * H, p->b_ih[l], B, 3 * H, in_dim,
+                                1.f, 0.f, stream));
+            TRY(dssvae_gemm_f32(hl, H, 0, nullptr, p->w_hh[l], H, 0, w.gh, 3 * H, p->b_hh[l], B, 3 * H, H, 1.f, 0.f,
+                                stream));
+            TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
+            in = hl;
+            in_dim = H;
+        }
+        TRY(dssvae_linear_lse_fwd(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, n_split, w.pmax, w.psum,
+                                  w.parg, 1, nullptr, 0, stream));
+        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, n_split, nullptr, w.tok, stream));
+        e = hipMemcpyAsync(tokens + (size_t)t * B, w.tok, (size_t)B * 8, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+#undef TRY
+    if (h_final) {
+        e = hipMemcpyAsync(h_final, w.h, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
+    return DSSVAE_OK;
+}

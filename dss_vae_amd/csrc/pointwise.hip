@@ -88,6 +88,64 @@ __global__ void gru_cell_kernel(const float* __restrict__ gi, const float* __res
     hn[i] = (1.f - z) * n + z * h[i];
 }
 
+// One timestep of a GRU whose recurrent product gh = h_{t-1} W_hh^T was made by the GEMM (the stepwise
+// path for instances too large for the persistent kernel).  Same saved history layout as gru_fwd_kernel:
+// gates row = [r | z | n | W_hn h + b_hn | h_{t-1}].  Rows with t >= len keep their state, output 0.
+__global__ void gru_step_fwd_kernel(const float* __restrict__ x, int64_t x_rs, const float* __restrict__ gh,
+                                    const float* __restrict__ bhh, const float* __restrict__ h,
+                                    const int32_t* __restrict__ lengths, int t, int B, int H,
+                                    float* __restrict__ hn, float* __restrict__ out, int64_t out_rs,
+                                    float* __restrict__ gates, int64_t g_rs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H) return;
+    const int64_t b = i / H, u = i % H;
+    const float* a = x + b * x_rs;
+    const float* c = gh + b * 3 * H;
+    const float hp = h ? h[i] : 0.f;
+    const float r = sigmoidf_(a[u] + c[u] + bhh[u]);
+    const float z = sigmoidf_(a[H + u] + c[H + u] + bhh[H + u]);
+    const float m = c[2 * H + u] + bhh[2 * H + u];
+    const float n = tanhf(a[2 * H + u] + r * m);
+    const float hv = (1.f - z) * n + z * hp;
+    const bool live = !lengths || t < lengths[b];
+    hn[i] = live ? hv : hp;
+    if (out) out[b * out_rs + u] = live ? hv : 0.f;
+    if (gates) {
+        float* g = gates + b * g_rs;
+        g[u] = r; g[H + u] = z; g[2 * H + u] = n; g[3 * H + u] = m; g[4 * H + u] = hp;
+    }
+}
+
+// Backward of one timestep: dh (gradient wrt h_t from the future) + dout_t -> dgx_t, dgh_t [3H] and
+// dhz = the part of dh_{t-1} that does not go through W_hh (the caller adds dgh_t . W_hh by GEMM).
+__global__ void gru_step_bwd_kernel(const float* __restrict__ gates, int64_t g_rs, const float* __restrict__ dout,
+                                    int64_t d_rs, const float* __restrict__ dh, const int32_t* __restrict__ lengths,
+                                    int t, int B, int H, float* __restrict__ dgx, float* __restrict__ dgh,
+                                    int64_t o_rs, float* __restrict__ dhz) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * H) return;
+    const int64_t b = i / H, u = i % H;
+    const float gin = dh ? dh[i] : 0.f;
+    float* ox = dgx + b * o_rs;
+    float* oh = dgh + b * o_rs;
+    const bool live = !lengths || t < lengths[b];
+    if (!live) {
+        ox[u] = ox[H + u] = ox[2 * H + u] = 0.f;
+        oh[u] = oh[H + u] = oh[2 * H + u] = 0.f;
+        dhz[i] = gin;
+        return;
+    }
+    const float* gs = gates + b * g_rs;
+    const float r = gs[u], z = gs[H + u], n = gs[2 * H + u], m = gs[3 * H + u], hp = gs[4 * H + u];
+    const float g = gin + (dout ? dout[b * d_rs + u] : 0.f);
+    const float dn = g * (1.f - z) * (1.f - n * n);
+    const float dz = g * (hp - n) * z * (1.f - z);
+    const float dr = dn * m * r * (1.f - r);
+    ox[u] = dr; ox[H + u] = dz; ox[2 * H + u] = dn;
+    oh[u] = dr; oh[H + u] = dz; oh[2 * H + u] = dn * r;
+    dhz[i] = g * z;
+}
+
 __global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
     float acc = 0.f;
     const int64_t n4 = n >> 2;
@@ -199,6 +257,34 @@ extern "C" int dssvae_gru_cell(const float* gi, const float* gh, const float* h,
     const int64_t n = (int64_t)B * H;
     hipLaunchKernelGGL(gru_cell_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
                        h, B, H, h_new);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_gru_step_fwd(const float* x_t, int64_t x_row_stride, const float* gh, const float* bhh,
+                                   const float* h_prev, const int32_t* lengths, int t, int B, int H, float* h_new,
+                                   float* out_t, int64_t out_row_stride, float* gates_t, int64_t gates_row_stride,
+                                   void* stream) {
+    if (!x_t || !gh || !bhh || !h_new || B <= 0 || H <= 0 || x_row_stride < 3 * H) return DSSVAE_EINVAL;
+    if ((out_t && out_row_stride < H) || (gates_t && gates_row_stride < 5 * H)) return DSSVAE_EINVAL;
+    const int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(gru_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_t,
+                       x_row_stride, gh, bhh, h_prev, lengths, t, B, H, h_new, out_t, out_row_stride, gates_t,
+                       gates_row_stride);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_stride, const float* dout_t,
+                                   int64_t dout_row_stride, const float* dh, const int32_t* lengths, int t, int B,
+                                   int H, float* dgx_t, float* dgh_t, int64_t dg_row_stride, float* dhz, void* stream) {
+    if (!gates_t || !dgx_t || !dgh_t || !dhz || B <= 0 || H <= 0 || gates_row_stride < 5 * H ||
+        dg_row_stride < 3 * H || (dout_t && dout_row_stride < H))
+        return DSSVAE_EINVAL;
+    const int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gates_t, gates_row_stride, dout_t, dout_row_stride, dh, lengths, t, B, H, dgx_t, dgh_t,
+                       dg_row_stride, dhz);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

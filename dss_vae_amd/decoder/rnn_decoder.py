@@ -84,25 +84,13 @@ class RNNDecoder(RNNBase):
     # ---- greedy generation ---------------------------------------------------------------------
     @torch.no_grad()
     def greedy_tokens(self, encoder_hidden, max_length=None):
-        """always max_length steps from <s> (rnn_decoder.py:160-168,193-199) -> int64 [max_len,B].
-        Per step: embedding rows, 2 small GEMMs + fused cell per layer, projection fused with argmax."""
+        """always max_length steps from <s> (rnn_decoder.py:160-168,193-199) -> (int64 [max_len,B], h_T).
+        The whole loop is one native call: per step embedding rows, 2 small GEMMs + fused cell per
+        layer, projection fused with the arg-max; no host round trip per step."""
         max_length = self.max_length if max_length is None else max_length
-        B = encoder_hidden.size(1)
-        dev = encoder_hidden.device
-        tok = torch.full((B,), self.sos_id, dtype=torch.int64, device=dev)
-        h = [encoder_hidden[l].contiguous() for l in range(self.n_layers)]
         params = [self.rnn.layer_params(l) for l in range(self.n_layers)]
-        table = self.embedding.weight
-        seq = torch.empty(max_length, B, dtype=torch.int64, device=dev)
-        for t in range(max_length):
-            emb = ops.embed(table, tok, None)
-            x = emb
-            for l, (wih, whh, bih, bhh) in enumerate(params):
-                h[l] = ops.gru_cell(ops.mm_nt(x, wih, bih), ops.mm_nt(h[l], whh, bhh), h[l])
-                x = h[l]
-            tok = ops.linear_argmax(x, emb, self.out.weight, self.out.bias)
-            seq[t] = tok
-        return seq, torch.stack(h, 0)
+        return ops.greedy_decode(self.embedding.weight, params, self.out.weight, self.out.bias, encoder_hidden,
+                                 self.sos_id, max_length)
 
     def forward(self, inputs=None, encoder_hidden=None, encoder_outputs=None, function=F.log_softmax,
                 teacher_forcing_ratio=0.0):

@@ -33,6 +33,17 @@ class GruBwdInst(C.Structure):
                 ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32)]
 
 
+DECODE_MAX_LAYERS = 4
+
+
+class DecodeParams(C.Structure):
+    _fields_ = [("embedding", C.c_void_p), ("ld_embedding", C.c_int64), ("n_embeddings", C.c_int64),
+                ("w_ih", C.c_void_p * DECODE_MAX_LAYERS), ("w_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("b_ih", C.c_void_p * DECODE_MAX_LAYERS), ("b_hh", C.c_void_p * DECODE_MAX_LAYERS),
+                ("w_out", C.c_void_p), ("ld_out", C.c_int64), ("b_out", C.c_void_p),
+                ("E", C.c_int32), ("H", C.c_int32), ("V", C.c_int32), ("n_layers", C.c_int32)]
+
+
 _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _SIGNATURES = {
     "dssvae_abi_version": ([], _I),
@@ -57,6 +68,10 @@ _SIGNATURES = {
     "dssvae_gru_bwd": ([C.POINTER(GruBwdInst), _I, _P, _L, _P], _I),
     "dssvae_gru_check": ([_P, _P], _I),
     "dssvae_gru_cell": ([_P, _P, _P, _I, _I, _P, _P], _I),
+    "dssvae_gru_step_fwd": ([_P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _P], _I),
+    "dssvae_gru_step_bwd": ([_P, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P], _I),
+    "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I], _L),
+    "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),
     "dssvae_sumsq": ([_P, _L, _P, _P], _I),
     "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P], _I),
 }

@@ -477,6 +477,66 @@ def linear_argmax(xh, xe, W, b):
 # ----------------------------------------------------------------------------------------------
 # Persistent GRU
 # ----------------------------------------------------------------------------------------------
+GRU_LDS_BUDGET = 150 * 1024
+FORCE_STEPWISE_GRU = False  # tests: send every recurrence down the stepwise path
+
+
+def _fits_persistent(B, H):
+    """can one persistent launch hold this recurrence?  (one workgroup per CU for 64 rows x 16 units,
+    its W_hh slice 3 x 16 x H fp32 resident in LDS)"""
+    ns = (H + 15) // 16
+    if FORCE_STEPWISE_GRU:
+        return False
+    return ((B + 63) // 64) * ns <= n_cus() and 3 * ns * 1024 <= GRU_LDS_BUDGET
+
+
+def _gru_steps_fwd(x, whh, bhh, h0, lengths, reverse, o, col, hl, gates):
+    """stepwise forward of one recurrence too large for the persistent kernel: per timestep the
+    recurrent product on the MFMA GEMM (at these sizes the step is compute-bound) + the fused gate kernel"""
+    B, T, _ = x.shape
+    H = whh.size(1)
+    dev = x.device
+    lib = L.load()
+    h = torch.zeros(B, H, device=dev, dtype=torch.float32) if h0 is None else h0
+    gh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+    nxt = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+    ldx, W = _xproj_ld(x), o.size(2)
+    lp = None if lengths is None else lengths.data_ptr()
+    for step in range(T):
+        t = T - 1 - step if reverse else step
+        mm_nt(h, whh, out=gh)
+        hn = hl if step == T - 1 else nxt[step & 1]
+        with _Span("gru_step_kernel", 0.0, 4.0 * B * H * (3 + 3 + 1 + 2 + (5 if gates is not None else 0))):
+            L.check(lib.dssvae_gru_step_fwd(
+                x.data_ptr() + 4 * t * ldx, T * ldx, L.ptr(gh), L.ptr(bhh), L.ptr(h), lp, t,
+                B, H, L.ptr(hn), o.data_ptr() + 4 * (t * W + col), T * W,
+                None if gates is None else gates.data_ptr() + 4 * t * 5 * H, T * 5 * H, L.stream()),
+                "dssvae_gru_step_fwd")
+        h = hn
+
+
+def _gru_steps_bwd(whh, gates, lengths, reverse, do, col, dhl, dgx, dgh, dh0):
+    B, T, K = dgx.shape
+    H = K // 3
+    dev = dgx.device
+    lib = L.load()
+    buf = [torch.empty(B, H, device=dev, dtype=torch.float32) for _ in range(2)]
+    dh = dhl
+    lp = None if lengths is None else lengths.data_ptr()
+    for step in range(T):
+        fstep = T - 1 - step
+        t = T - 1 - fstep if reverse else fstep
+        dhz = dh0 if step == T - 1 else buf[step & 1]
+        with _Span("gru_step_kernel", 0.0, 4.0 * B * H * 13):
+            L.check(lib.dssvae_gru_step_bwd(
+                gates.data_ptr() + 4 * t * 5 * H, T * 5 * H,
+                None if do is None else do.data_ptr() + 4 * (t * do.size(2) + col), 0 if do is None else T * do.size(2),
+                L.ptr(dh), lp, t, B, H, dgx.data_ptr() + 4 * t * K, dgh.data_ptr() + 4 * t * K, T * K, L.ptr(dhz),
+                L.stream()), "dssvae_gru_step_bwd")
+        mm_nn(dgh[:, t, :], whh, out=dhz, beta=1.0)
+        dh = dhz
+
+
 def _pack(insts):
     """Group instances (B, H, T) into persistent launches whose workgroups are co-resident (one per
     CU) and that hold <= 8 instances, longest recurrences first (first-fit decreasing on T): a
@@ -540,7 +600,17 @@ class _GruFn(Function):
         bs = [b.contiguous() for b in bs]
         h0s = [None if h.numel() == 0 else h.contiguous() for h in h0s]
         lib = L.load()
-        for launch in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in range(n)]):
+        fit = [_fits_persistent(BT[i][0], Hs[i]) for i in range(n)]
+        ctx.fit = fit
+        for i in range(n):
+            if not fit[i]:
+                o = outs[meta["group"][i]]
+                assert (o.size(0), o.size(1)) == BT[i]
+                _gru_steps_fwd(xs[i], ws[i], bs[i], h0s[i], lengths, bool(meta["reverse"][i]), o, meta["col"][i],
+                               hl[i], gates[i])
+        pers = [i for i in range(n) if fit[i]]
+        for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in pers]):
+            launch = [pers[k] for k in launch_]
             arr = (L.GruFwdInst * len(launch))()
             for k, i in enumerate(launch):
                 o = outs[meta["group"][i]]
@@ -588,8 +658,13 @@ class _GruFn(Function):
             dgh[i] = torch.empty(BT[i][0], BT[i][1], 3 * Hs[i], device=dev, dtype=torch.float32)
             dh0[i] = torch.empty(BT[i][0], Hs[i], device=dev, dtype=torch.float32)
         lib = L.load()
-        for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live]):
-            launch = [live[k] for k in launch_]
+        for i in live:
+            if not ctx.fit[i]:
+                _gru_steps_bwd(ws[i], gates[i], lengths, bool(meta["reverse"][i]), douts[meta["group"][i]],
+                               meta["col"][i], dhl[i], dgx[i], dgh[i], dh0[i])
+        live_p = [i for i in live if ctx.fit[i]]
+        for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live_p]):
+            launch = [live_p[k] for k in launch_]
             arr = (L.GruBwdInst * len(launch))()
             for k, i in enumerate(launch):
                 do = douts[meta["group"][i]]
@@ -655,6 +730,39 @@ def gru_cell(gi, gh, h):
     L.check(L.load().dssvae_gru_cell(L.ptr(gi.contiguous()), L.ptr(gh.contiguous()), L.ptr(h.contiguous()), h.size(0),
                                      h.size(1), L.ptr(out), L.stream()), "dssvae_gru_cell")
     return out
+
+
+def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
+    """whole greedy loop in one native call (dssvae_greedy_decode): -> (tokens [max_len,B] int64,
+    h_final [layers,B,H]).  layers: list of (w_ih, w_hh, b_ih, b_hh)."""
+    L.require_cuda(table, w_out, h0)
+    n_layers, B, H = h0.shape
+    E, V = table.size(1), w_out.size(0)
+    assert len(layers) == n_layers <= L.DECODE_MAX_LAYERS and w_out.size(1) == H + E
+    keep = [_f32(table), _f32(w_out)] + [None if b_out is None else b_out.contiguous()]
+    prm = L.DecodeParams()
+    prm.embedding, prm.ld_embedding, prm.n_embeddings = table.data_ptr(), table.stride(0), table.size(0)
+    for l, ps in enumerate(layers):
+        ps = [_f32(t).contiguous() for t in ps]
+        keep += ps
+        assert ps[0].shape == (3 * H, E if l == 0 else H) and ps[1].shape == (3 * H, H)
+        prm.w_ih[l], prm.w_hh[l], prm.b_ih[l], prm.b_hh[l] = (t.data_ptr() for t in ps)
+    prm.w_out, prm.ld_out = w_out.data_ptr(), w_out.stride(0)
+    prm.b_out = None if keep[2] is None else keep[2].data_ptr()
+    prm.E, prm.H, prm.V, prm.n_layers = E, H, V, n_layers
+    S = _pick_split(B, V)
+    lib = L.load()
+    nbytes = lib.dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, S)
+    if nbytes <= 0:
+        raise RuntimeError("dssvae_greedy_decode_workspace_bytes rejected the shape")
+    dev = h0.device
+    wsb = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    tokens = torch.empty(max_len, B, device=dev, dtype=torch.int64)
+    h_fin = torch.empty(n_layers, B, H, device=dev, dtype=torch.float32)
+    h0 = _f32(h0).contiguous()
+    L.check(lib.dssvae_greedy_decode(C.byref(prm), L.ptr(h0), B, int(max_len), int(sos_id), S, L.ptr(tokens),
+                                     L.ptr(h_fin), L.ptr(wsb), nbytes, L.stream()), "dssvae_greedy_decode")
+    return tokens, h_fin
 
 
 # ----------------------------------------------------------------------------------------------

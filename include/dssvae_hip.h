@@ -186,6 +186,47 @@ int dssvae_gru_check(void* workspace, void* stream);
 int dssvae_gru_cell(const float* gi, const float* gh, const float* h, int B, int H, float* h_new,
                     void* stream);
 
+/* Stepwise GRU (same reference call sites as the persistent kernel): for recurrences too large for
+ * the persistent kernel's residency budget (W_hh slice in LDS, one workgroup per CU: e.g. the stress
+ * configuration's H = 2048 decoder) the caller computes gh = h_{t-1} W_hh^T with dssvae_gemm_f32 --
+ * at those sizes the step is MFMA-bound, not latency-bound -- and these fuse the gate math of ONE
+ * timestep.  Pointers are pre-offset to timestep t; *_row_stride = elements between batch rows.
+ * fwd: h_new [B,H]; out_t (may be NULL); gates_t (may be NULL) in the layout of dssvae_gru_fwd.
+ * bwd: dh [B,H] = gradient wrt h_t arriving from t+1 (NULL = 0), dout_t (may be NULL);
+ *      writes dgx_t, dgh_t [B,3H] and dhz [B,H]; the caller forms dh_{t-1} = dhz + dgh_t W_hh. */
+int dssvae_gru_step_fwd(const float* x_t, int64_t x_row_stride, const float* gh, const float* bhh,
+                        const float* h_prev, const int32_t* lengths, int t, int B, int H, float* h_new,
+                        float* out_t, int64_t out_row_stride, float* gates_t, int64_t gates_row_stride,
+                        void* stream);
+int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_stride, const float* dout_t,
+                        int64_t dout_row_stride, const float* dh, const int32_t* lengths, int t, int B, int H,
+                        float* dgx_t, float* dgh_t, int64_t dg_row_stride, float* dhz, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Greedy generation (RNNDecoder.forward with inputs=None: decoder/rnn_decoder.py:160-168,193-199;
+ * BaseVAE.decode_to_sentence, vae/base_vae.py:169-190; RNNPredictor.predict,
+ * vae/enhance_syntax_vae.py:581-592): always max_len steps from <s>; per step embedding rows ->
+ * n_layers GRU cells -> [h;e] W_out^T + b fused with the arg-max over the vocabulary.  One call
+ * enqueues the whole loop on `stream`; nothing is allocated, synchronised or copied to the host.
+ *   h0 [n_layers,B,H]; tokens [max_len,B] int64 (out); h_final [n_layers,B,H] (out, may be NULL)
+ *   n_split: vocabulary splits of the fused projection/arg-max (<= ceil(V/128))
+ *   workspace: dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, n_split) bytes, 16-B aligned
+ * ------------------------------------------------------------------------------------------- */
+#define DSSVAE_DECODE_MAX_LAYERS 4
+typedef struct {
+    const float* embedding; int64_t ld_embedding; int64_t n_embeddings;   /* [n_embeddings, E] */
+    const float* w_ih[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, E] for layer 0, [3H, H] above */
+    const float* w_hh[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, H] */
+    const float* b_ih[DSSVAE_DECODE_MAX_LAYERS];
+    const float* b_hh[DSSVAE_DECODE_MAX_LAYERS];
+    const float* w_out; int64_t ld_out; const float* b_out;                /* [V, H+E], [V] or NULL */
+    int32_t E, H, V, n_layers;
+} dssvae_decode_params;
+int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split);
+int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, int B, int max_len,
+                         int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers (bin/train.py:124-126, utils/model_utils.py:195):
  * sumsq_out[0] += sum(g^2);  Adam step with bias correction and the clip coefficient

@@ -179,9 +179,12 @@ def gru_reference(x, h0, wih, whh, bih, bhh, lengths, reverse):
 
 @pytest.mark.parametrize("B,T,H,I,packed", [(3, 4, 8, 5, False), (70, 6, 30, 12, True), (64, 9, 150, 20, True),
                                             (130, 5, 300, 16, False), (256, 4, 600, 8, False)])
-def test_persistent_gru_forward_backward(B, T, H, I, packed):
-    """two instances (forward + reverse direction) in one persistent launch, vs explicit equations"""
+@pytest.mark.parametrize("stepwise", [False, True])
+def test_persistent_gru_forward_backward(B, T, H, I, packed, stepwise, monkeypatch):
+    """two instances (forward + reverse direction) in one persistent launch -- or, stepwise=True, down the
+    per-timestep GEMM + gate-kernel path that oversized recurrences take -- vs explicit equations"""
     from dss_vae_amd import ops
+    monkeypatch.setattr(ops, "FORCE_STEPWISE_GRU", stepwise)
     g = torch.Generator().manual_seed(B + H)
     lengths = None
     if packed:
@@ -244,6 +247,50 @@ def test_gru_cell_and_no_h0():
     o, hT = oracle.gru_loop(x, torch.zeros(5, 20), eye, whh, torch.zeros(60), bhh)
     close(out, o, what="out no h0")
     close(hl, hT, what="hl no h0")
+
+
+def test_oversized_gru_takes_the_stepwise_path():
+    """H = 1024 does not fit the persistent kernel's LDS budget (3 * 64 slices * 1 KiB > 150 KiB)"""
+    from dss_vae_amd import ops
+    assert not ops._fits_persistent(8, 1024) and not ops._fits_persistent(1024, 512) and ops._fits_persistent(256, 600)
+    B, T, H = 8, 3, 1024
+    x, whh, bhh, h0 = rnd(B, T, 3 * H, seed=4), rnd(3 * H, H, seed=5, scale=0.03), rnd(3 * H, seed=6), rnd(B, H, seed=7)
+    with torch.no_grad():
+        (out,), (hl,) = ops.gru_layer([dict(xproj=x.to(DEV), whh=whh.to(DEV), bhh=bhh.to(DEV), h0=h0.to(DEV), group=0,
+                                            col=0)], save=False)
+    import oracle
+    o, hT = oracle.gru_loop(x, h0, torch.eye(3 * H), whh, torch.zeros(3 * H), bhh)
+    close(out, o, rtol=1e-4, atol=1e-4, what="out")
+    close(hl, hT, rtol=1e-4, atol=1e-4, what="hl")
+
+
+@pytest.mark.parametrize("B,E,H,V,layers,T", [(5, 12, 20, 97, 1, 6), (50, 300, 600, 3001, 2, 9)])
+def test_native_greedy_decode_loop(B, E, H, V, layers, T):
+    """dssvae_greedy_decode (whole loop, one call) vs an explicit fp64 loop of the reference's step"""
+    from dss_vae_amd import ops
+    table = rnd(V, E, seed=1, scale=0.5)
+    ps = [(rnd(3 * H, E if l == 0 else H, seed=10 + l, scale=0.2), rnd(3 * H, H, seed=20 + l, scale=0.2),
+           rnd(3 * H, seed=30 + l, scale=0.2), rnd(3 * H, seed=40 + l, scale=0.2)) for l in range(layers)]
+    wo, bo, h0 = rnd(V, H + E, seed=2, scale=0.5), rnd(V, seed=3), rnd(layers, B, H, seed=4)
+    tok = torch.full((B,), 1, dtype=torch.int64)
+    h = [h0[l].double() for l in range(layers)]
+    want = []
+    for _ in range(T):
+        e = table.double()[tok]
+        x = e
+        for l, (wih, whh, bih, bhh) in enumerate(ps):
+            gi, gh = x @ wih.double().t() + bih.double(), h[l] @ whh.double().t() + bhh.double()
+            r = torch.sigmoid(gi[:, :H] + gh[:, :H])
+            z = torch.sigmoid(gi[:, H:2 * H] + gh[:, H:2 * H])
+            n = torch.tanh(gi[:, 2 * H:] + r * gh[:, 2 * H:])
+            h[l] = (1 - z) * n + z * h[l]
+            x = h[l]
+        tok = (torch.cat((x, e), 1) @ wo.double().t() + bo.double()).argmax(1)
+        want.append(tok)
+    got, hf = ops.greedy_decode(table.to(DEV), [tuple(t.to(DEV) for t in p) for p in ps], wo.to(DEV), bo.to(DEV),
+                                h0.to(DEV), 1, T)
+    assert torch.equal(got.cpu(), torch.stack(want, 0))
+    close(hf, torch.stack(h, 0), rtol=1e-4, atol=1e-4, what="h_final")
 
 
 def test_sumsq_and_adam():
