@@ -42,12 +42,23 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
+
+// partial columns: enough for the general kernel's n_split and for the skinny kernel's own split count
+// (at most one 16-column block per workgroup)
+inline int part_cols(int n_split, int V) { return max(n_split, (V + 15) / 16); }
+
+// [X | X2] W^T + b: the skinny kernel when the shape is in its range, else the tiled GEMM (X2 == NULL there)
+int small_linear(const float* X, int K, const float* W, const float* b, int B, int N, float* C, void* stream) {
+    int rc = dssvae_skinny_linear(X, K, K, nullptr, 0, 0, W, K, b, B, N, C, N, stream);
+    if (rc == DSSVAE_ETOOBIG) rc = dssvae_gemm_f32(X, K, 0, nullptr, W, K, 0, C, N, b, B, N, K, 1.f, 0.f, stream);
+    return rc;
+}
 }  // namespace
 
-extern "C" int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split) {
-    if (B <= 0 || E <= 0 || H <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
+extern "C" int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V) {
+    if (B <= 0 || E <= 0 || H <= 0 || V <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
         return DSSVAE_EINVAL;
-    return (int64_t)carve(nullptr, B, E, H, n_layers, n_split).bytes;
+    return (int64_t)carve(nullptr, B, E, H, n_layers, part_cols(n_split, V)).bytes;
 }
 
 extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* h0, int B, int max_len,
@@ -61,7 +72,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     for (int l = 0; l < L; ++l)
         if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return DSSVAE_EINVAL;
     if (!aligned16(workspace)) return DSSVAE_EINVAL;
-    const Ws w = carve(workspace, B, E, H, L, n_split);
+    const Ws w = carve(workspace, B, E, H, L, part_cols(n_split, V));
     if ((int64_t)w.bytes > workspace_bytes) return DSSVAE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemcpyAsync(w.h, h0, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
@@ -76,17 +87,22 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
         int in_dim = E;
         for (int l = 0; l < L; ++l) {
             float* hl = w.h + (size_t)l * B * H;
-            TRY(dssvae_gemm_f32(in, in_dim, 0, nullptr, p->w_ih[l], in_dim, 0, w.gi, 3 * H, p->b_ih[l], B, 3 * H, in_dim,
-                                1.f, 0.f, stream));
-            TRY(dssvae_gemm_f32(hl, H, 0, nullptr, p->w_hh[l], H, 0, w.gh, 3 * H, p->b_hh[l], B, 3 * H, H, 1.f, 0.f,
-                                stream));
+            TRY(small_linear(in, in_dim, p->w_ih[l], p->b_ih[l], B, 3 * H, w.gi, stream));
+            TRY(small_linear(hl, H, p->w_hh[l], p->b_hh[l], B, 3 * H, w.gh, stream));
             TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
             in = hl;
             in_dim = H;
         }
-        TRY(dssvae_linear_lse_fwd(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, n_split, w.pmax, w.psum,
-                                  w.parg, 1, nullptr, 0, stream));
-        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, n_split, nullptr, w.tok, stream));
+        int S = dssvae_skinny_argmax_splits(B, V);
+        rc = dssvae_skinny_argmax(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, w.pmax, w.psum, w.parg,
+                                  stream);
+        if (rc == DSSVAE_ETOOBIG) {
+            S = n_split;
+            rc = dssvae_linear_lse_fwd(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, n_split, w.pmax,
+                                       w.psum, w.parg, 1, nullptr, 0, stream);
+        }
+        if (rc != DSSVAE_OK) return rc;
+        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, S, nullptr, w.tok, stream));
         e = hipMemcpyAsync(tokens + (size_t)t * B, w.tok, (size_t)B * 8, hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) return (int)e;
     }

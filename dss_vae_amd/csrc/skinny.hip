@@ -1,0 +1,231 @@
+// Skinny projections for the generation loop (M = a decode batch of a few dozen rows):
+//   C[M,N] = [X1 | X2] . W^T + bias            (GRU gate pre-activations of one step)
+//   argmax_n ([X1 | X2] . W^T + bias)[m, n]    (greedy token: decoder/rnn_decoder.py:70-73 + topk(1))
+// At M <= 128 the 128x128 LDS-tiled GEMM wastes most of its tile and runs a handful of workgroups;
+// here the problem is what it really is, a stream over W (108 MB for the 30k-vocabulary projection,
+// resident in the Infinity Cache between steps): the 32 activation rows of a workgroup sit in LDS for
+// the whole kernel, every wave streams 16 rows of W at a time straight from memory into the A operand
+// of v_mfma_f32_16x16x4_f32 (exact fp32) with register double-buffered prefetch, and applies them to
+// both 16-row activation tiles.  Bound: HBM / Infinity-Cache bandwidth (2 flop per byte of W per tile).
+#include "common.h"
+
+namespace {
+
+constexpr int SK_ROWS = 32;       // activation rows per workgroup (2 MFMA tiles of 16)
+constexpr int SK_THREADS = 512;   // 8 waves
+constexpr int SK_WAVES = SK_THREADS / 64;
+constexpr int SK_GC = 4;          // k-groups (16 k each) per register chunk
+constexpr int SK_LDS_BUDGET = 150 * 1024;
+constexpr float SK_NEG = -3.0e38f;
+
+// row stride of the LDS image: multiple of 16 k plus 4 floats => stride = 4 (mod 8) floats, so the 16 rows
+// read by one 16-lane group of a ds_read_b128 fall into 16 distinct 4-bank slots (conflict-free)
+inline int padded_k(int K) { return ((K + 15) / 16) * 16 + 4; }
+
+template <bool ARGMAX>
+__global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
+    const float* __restrict__ X1, int64_t ld1, int K1, const float* __restrict__ X2, int64_t ld2, int K2,
+    const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp,
+    int blocks_per_wg, float* __restrict__ C, int64_t ldc, int cvec, float* __restrict__ part_max,
+    float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp]
+    __shared__ float red_v[SK_WAVES][SK_ROWS];
+    __shared__ int red_i[SK_WAVES][SK_ROWS];
+    const int K = K1 + K2;
+    const int m0 = blockIdx.y * SK_ROWS;
+    const int kp4 = Kp >> 2;
+    for (int idx = threadIdx.x; idx < SK_ROWS * kp4; idx += SK_THREADS) {
+        const int r = idx / kp4, k = (idx - r * kp4) << 2;
+        const int m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M && k < K)
+            v = k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
+                       : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
+        *reinterpret_cast<float4*>(Xs + r * Kp + k) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nG = (K + 15) >> 4;
+    const int NB = (N + 15) >> 4;
+    const int b_begin = blockIdx.x * blocks_per_wg, b_end = min(NB, b_begin + blocks_per_wg);
+    float best_v[2] = {SK_NEG, SK_NEG};
+    int best_i[2] = {0, 0};
+    const float* xs0 = Xs + r16 * Kp + 4 * kq;
+    const float* xs1 = xs0 + 16 * Kp;
+
+    for (int blk = b_begin + wave; blk < b_end; blk += SK_WAVES) {
+        const int n = min(blk * 16 + r16, N - 1);  // clamped rows are computed but never used
+        const float* wrow = W + (int64_t)n * ldw + 4 * kq;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 cur[SK_GC], nxt[SK_GC];
+#pragma unroll
+        for (int i = 0; i < SK_GC; ++i) {
+            const bool ok = i < nG && 16 * i + 4 * kq < K;
+            cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int g0 = 0; g0 < nG; g0 += SK_GC) {
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) {
+                const int g = g0 + SK_GC + i;
+                const bool ok = g < nG && 16 * g + 4 * kq < K;
+                nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) {
+                if (g0 + i < nG) {
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x0[j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x1[j], acc1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+        }
+        // lane holds columns nb..nb+3 of activation rows (m0 + r16) and (m0 + 16 + r16)
+        const int nb = blk * 16 + 4 * kq;
+        float bv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bv[r] = (bias && nb + r < N) ? bias[nb + r] : 0.f;
+        if (ARGMAX) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (nb + r < N) {
+                    const float v0 = acc0[r] + bv[r], v1 = acc1[r] + bv[r];
+                    if (v0 > best_v[0]) { best_v[0] = v0; best_i[0] = nb + r; }
+                    if (v1 > best_v[1]) { best_v[1] = v1; best_i[1] = nb + r; }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = m0 + mt * 16 + r16;
+                if (m >= M) continue;
+                const f32x4 a = mt == 0 ? acc0 : acc1;
+                float* c = C + (int64_t)m * ldc + nb;
+                if (cvec && nb + 3 < N) {
+                    *reinterpret_cast<float4*>(c) = make_float4(a[0] + bv[0], a[1] + bv[1], a[2] + bv[2], a[3] + bv[3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (nb + r < N) c[r] = a[r] + bv[r];
+                }
+            }
+        }
+    }
+    if (!ARGMAX) return;
+    // best over the 4 lane groups of the wave (ties: the smaller column), then over the 8 waves
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        float v = best_v[mt];
+        int ix = best_i[mt];
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float v2 = __shfl_xor(v, o, 64);
+            const int i2 = __shfl_xor(ix, o, 64);
+            if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        }
+        if (kq == 0) { red_v[wave][mt * 16 + r16] = v; red_i[wave][mt * 16 + r16] = ix; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SK_ROWS) {
+        const int m = m0 + threadIdx.x;
+        if (m < M) {
+            float v = red_v[0][threadIdx.x];
+            int ix = red_i[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) {
+                const float v2 = red_v[w][threadIdx.x];
+                const int i2 = red_i[w][threadIdx.x];
+                if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+            }
+            part_max[(int64_t)m * n_split + blockIdx.x] = v;
+            part_sum[(int64_t)m * n_split + blockIdx.x] = 1.f;
+            part_arg[(int64_t)m * n_split + blockIdx.x] = ix;
+        }
+    }
+}
+
+int sk_cus() {
+    static int cus = 0;
+    if (cus == 0) {
+        int n = 0;
+        if (dssvae_device_cus(&n) != 0 || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+bool sk_ok(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2, const float* W, int64_t ldw,
+           int M) {
+    if (M > DSSVAE_SKINNY_MAX_ROWS) return false;
+    if ((K1 % 4) || (K2 % 4) || (ld1 % 4) || (ldw % 4) || !aligned16(X1) || !aligned16(W)) return false;
+    if (K2 > 0 && ((ld2 % 4) || !aligned16(X2))) return false;
+    return SK_ROWS * padded_k(K1 + K2) * 4 <= SK_LDS_BUDGET;
+}
+
+template <bool ARGMAX>
+int sk_launch(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2, const float* W,
+              int64_t ldw, const float* bias, int M, int N, int bpw, int n_wg, float* C, int64_t ldc, float* pm,
+              float* ps, int64_t* pa, hipStream_t s) {
+    const int Kp = padded_k(K1 + K2);
+    const int lds = SK_ROWS * Kp * 4;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<ARGMAX>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int cvec = C && aligned16(C) && (ldc % 4) == 0;
+    hipLaunchKernelGGL(skinny_kernel<ARGMAX>, dim3(n_wg, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds, s, X1,
+                       ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, Kp, bpw, C, ldc, cvec, pm, ps, pa, n_wg);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+// 16-column blocks per workgroup so that the launch is about one workgroup per CU
+int argmax_bpw(int M, int N) {
+    const int NB = (N + 15) / 16, m_chunks = (M + SK_ROWS - 1) / SK_ROWS;
+    const int target = max(1, sk_cus() / m_chunks);
+    int bpw = (NB + target - 1) / target;
+    return (bpw + SK_WAVES - 1) / SK_WAVES * SK_WAVES;
+}
+
+}  // namespace
+
+extern "C" int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int64_t ldw) {
+    // alignment of the pointers is checked at the call; this answers for the shape
+    if (M <= 0 || M > DSSVAE_SKINNY_MAX_ROWS || K1 <= 0 || K2 < 0) return 0;
+    if ((K1 % 4) || (K2 % 4) || (ld1 % 4) || (ldw % 4) || (K2 > 0 && (ld2 % 4))) return 0;
+    return SK_ROWS * padded_k(K1 + K2) * 4 <= SK_LDS_BUDGET;
+}
+
+extern "C" int dssvae_skinny_argmax_splits(int M, int N) {
+    if (M <= 0 || N <= 0) return DSSVAE_EINVAL;
+    const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
+    return (NB + bpw - 1) / bpw;
+}
+
+extern "C" int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
+                                    const float* W, int64_t ldw, const float* bias, int M, int N, float* C,
+                                    int64_t ldc, void* stream) {
+    if (!X1 || !W || !C || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 || (K2 > 0 && !X2) || ld1 < K1 || ldw < K1 + K2 ||
+        ldc < N || (K2 > 0 && ld2 < K2))
+        return DSSVAE_EINVAL;
+    if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
+    const int NB = (N + 15) / 16;
+    return sk_launch<false>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, SK_WAVES, (NB + SK_WAVES - 1) / SK_WAVES, C,
+                            ldc, nullptr, nullptr, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
+                                    const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
+                                    float* part_sum, int64_t* part_arg, void* stream) {
+    if (!X1 || !W || !part_max || !part_sum || !part_arg || M <= 0 || N <= 0 || K1 <= 0 || K2 < 0 ||
+        (K2 > 0 && !X2) || ld1 < K1 || ldw < K1 + K2 || (K2 > 0 && ld2 < K2))
+        return DSSVAE_EINVAL;
+    if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
+    const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
+    return sk_launch<true>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
+                           part_max, part_sum, part_arg, (hipStream_t)stream);
+}

@@ -752,7 +752,7 @@ def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
     prm.E, prm.H, prm.V, prm.n_layers = E, H, V, n_layers
     S = _pick_split(B, V)
     lib = L.load()
-    nbytes = lib.dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, S)
+    nbytes = lib.dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, S, V)
     if nbytes <= 0:
         raise RuntimeError("dssvae_greedy_decode_workspace_bytes rejected the shape")
     dev = h0.device

@@ -202,6 +202,25 @@ int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_stride, const fl
                         int64_t dout_row_stride, const float* dh, const int32_t* lengths, int t, int B, int H,
                         float* dgx_t, float* dgh_t, int64_t dg_row_stride, float* dhz, void* stream);
 
+/* Skinny projections (M <= DSSVAE_SKINNY_MAX_ROWS activation rows: one decode batch), the per-step
+ * products of the greedy loop (decoder/rnn_decoder.py:61-73 called from :160-168):
+ *   dssvae_skinny_linear : C[M,N] = [X1 | X2] . W^T + bias
+ *   dssvae_skinny_argmax : per row, max and arg-max over n of the same product, as partials
+ *                          [M, S] with S = dssvae_skinny_argmax_splits(M, N) (part_sum is set to 1
+ *                          so that dssvae_lse_combine picks the winner)
+ * The activation rows stay in LDS, W is streamed once per 32 rows straight into the MFMA operand.
+ * X2 may be NULL (K2 = 0).  Returns DSSVAE_ETOOBIG when the shape is outside the kernel's range (rows,
+ * alignment to 4 floats, LDS budget): the caller then uses dssvae_gemm_f32 / dssvae_linear_lse_fwd. */
+#define DSSVAE_SKINNY_MAX_ROWS 128
+int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int64_t ldw);
+int dssvae_skinny_argmax_splits(int M, int N);
+int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
+                         const float* W, int64_t ldw, const float* bias, int M, int N, float* C, int64_t ldc,
+                         void* stream);
+int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
+                         const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
+                         float* part_sum, int64_t* part_arg, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Greedy generation (RNNDecoder.forward with inputs=None: decoder/rnn_decoder.py:160-168,193-199;
  * BaseVAE.decode_to_sentence, vae/base_vae.py:169-190; RNNPredictor.predict,
@@ -210,7 +229,7 @@ int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_stride, const fl
  * enqueues the whole loop on `stream`; nothing is allocated, synchronised or copied to the host.
  *   h0 [n_layers,B,H]; tokens [max_len,B] int64 (out); h_final [n_layers,B,H] (out, may be NULL)
  *   n_split: vocabulary splits of the fused projection/arg-max (<= ceil(V/128))
- *   workspace: dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, n_split) bytes, 16-B aligned
+ *   workspace: dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, n_split, V) bytes, 16-B aligned
  * ------------------------------------------------------------------------------------------- */
 #define DSSVAE_DECODE_MAX_LAYERS 4
 typedef struct {
@@ -222,7 +241,7 @@ typedef struct {
     const float* w_out; int64_t ld_out; const float* b_out;                /* [V, H+E], [V] or NULL */
     int32_t E, H, V, n_layers;
 } dssvae_decode_params;
-int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split);
+int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V);
 int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, int B, int max_len,
                          int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
                          int64_t workspace_bytes, void* stream);

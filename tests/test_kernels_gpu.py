@@ -293,6 +293,38 @@ def test_native_greedy_decode_loop(B, E, H, V, layers, T):
     close(hf, torch.stack(h, 0), rtol=1e-4, atol=1e-4, what="h_final")
 
 
+@pytest.mark.parametrize("M,K1,K2,N", [(1, 4, 0, 5), (50, 600, 300, 3001), (33, 300, 0, 1800), (128, 20, 12, 97)])
+def test_skinny_linear_and_argmax(M, K1, K2, N):
+    """C-ABI skinny kernels (decode-batch sized M) vs fp64 torch"""
+    from dss_vae_amd import lib as L
+    import ctypes as C
+    lib = L.load()
+    x1, x2 = rnd(M, K1, seed=1), (rnd(M, K2, seed=2) if K2 else None)
+    w, b = rnd(N, K1 + K2, seed=3, scale=0.3), rnd(N, seed=4)
+    xx = x1 if x2 is None else torch.cat((x1, x2), 1)
+    want = xx.double() @ w.double().t() + b.double()
+    d1, d2, dw, db = x1.to(DEV), None if x2 is None else x2.to(DEV), w.to(DEV), b.to(DEV)
+    assert lib.dssvae_skinny_supported(M, K1, K2, K1, K2, K1 + K2) == 1
+    assert lib.dssvae_skinny_supported(129, K1, K2, K1, K2, K1 + K2) == 0
+    out = torch.full((M, N), float("nan"), device=DEV)
+    L.check(lib.dssvae_skinny_linear(L.ptr(d1), K1, K1, L.ptr(d2), K2, K2, L.ptr(dw), K1 + K2, L.ptr(db), M, N,
+                                     L.ptr(out), N, L.stream()), "skinny_linear")
+    close(out, want, rtol=1e-4, atol=1e-4, what="skinny linear")
+    S = lib.dssvae_skinny_argmax_splits(M, N)
+    assert S >= 1
+    pm, ps = torch.empty(M, S, device=DEV), torch.empty(M, S, device=DEV)
+    pa = torch.empty(M, S, device=DEV, dtype=torch.int64)
+    L.check(lib.dssvae_skinny_argmax(L.ptr(d1), K1, K1, L.ptr(d2), K2, K2, L.ptr(dw), K1 + K2, L.ptr(db), M, N,
+                                     L.ptr(pm), L.ptr(ps), L.ptr(pa), L.stream()), "skinny_argmax")
+    arg = torch.empty(M, device=DEV, dtype=torch.int64)
+    L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, None, L.ptr(arg), L.stream()), "combine")
+    assert torch.equal(arg.cpu(), want.argmax(1))
+    close(pm.max(1).values, want.max(1).values, rtol=1e-4, atol=1e-4, what="max")
+    # out of range shapes are refused, not mangled
+    assert lib.dssvae_skinny_linear(L.ptr(d1), K1, K1, None, 0, 0, L.ptr(dw), K1 + K2, None, 129, N, L.ptr(out), N,
+                                    L.stream()) == -2
+
+
 def test_sumsq_and_adam():
     from dss_vae_amd import ops
     n = 100003
