@@ -440,21 +440,35 @@ __global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, cons
     }
 }
 
+// one wave per row: lanes stride over the splits, shuffle-reduce (max, first split holding it), then the
+// rescaled sum
 __global__ void lse_combine_kernel(const float* __restrict__ pm, const float* __restrict__ ps,
                                    const int64_t* __restrict__ pa, int M, int S, float* __restrict__ lse,
                                    int64_t* __restrict__ amax) {
-    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* rm = pm + (int64_t)m * S;
+    const float* rs = ps + (int64_t)m * S;
     float mx = NEG_BIG;
-    int best = 0;
-    for (int s = 0; s < S; ++s) {
-        const float v = pm[(int64_t)m * S + s];
+    int best = 0x7fffffff;
+    for (int s = lane; s < S; s += 64) {
+        const float v = rm[s];
         if (v > mx) { mx = v; best = s; }
     }
-    float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += ps[(int64_t)m * S + s] * __expf(pm[(int64_t)m * S + s] - mx);
-    if (lse) lse[m] = mx + __logf(acc);
-    if (amax && pa) amax[m] = pa[(int64_t)m * S + best];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o, 64);
+        const int b2 = __shfl_xor(best, o, 64);
+        if (m2 > mx || (m2 == mx && b2 < best)) { mx = m2; best = b2; }
+    }
+    if (lse) {
+        float acc = 0.f;
+        for (int s = lane; s < S; s += 64) acc += rs[s] * __expf(rm[s] - mx);
+        acc = wave_sum(acc);
+        if (lane == 0) lse[m] = mx + __logf(acc);
+    }
+    if (lane == 0 && amax && pa) amax[m] = pa[(int64_t)m * S + (best == 0x7fffffff ? 0 : best)];
 }
 
 // ---- DLOGITS -------------------------------------------------------------------------------------
@@ -720,7 +734,7 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
 extern "C" int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg, int M,
                                   int n_split, float* lse, int64_t* argmax, void* stream) {
     if (!part_max || !part_sum || M <= 0 || n_split <= 0) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(lse_combine_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, part_max,
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, part_max,
                        part_sum, part_arg, M, n_split, lse, argmax);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;

@@ -22,7 +22,11 @@ constexpr float SK_NEG = -3.0e38f;
 // read by one 16-lane group of a ds_read_b128 fall into 16 distinct 4-bank slots (conflict-free)
 inline int padded_k(int K) { return ((K + 15) / 16) * 16 + 4; }
 
-template <bool ARGMAX>
+// KS = waves that share one 16-column block, each taking a contiguous range of k (partials summed
+// through LDS).  The arg-max streams hundreds of blocks per workgroup (throughput-bound: KS = 1); the
+// gate pre-activation products have ~100 blocks in all and are latency-bound: KS = 4 shortens the
+// dependent chain of memory round trips per wave.
+template <bool ARGMAX, int KS>
 __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     const float* __restrict__ X1, int64_t ld1, int K1, const float* __restrict__ X2, int64_t ld2, int K2,
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp,
@@ -31,6 +35,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp]
     __shared__ float red_v[SK_WAVES][SK_ROWS];
     __shared__ int red_i[SK_WAVES][SK_ROWS];
+    __shared__ __attribute__((aligned(16))) float part[KS > 1 ? SK_WAVES : 1][2][64][4];
     const int K = K1 + K2;
     const int m0 = blockIdx.y * SK_ROWS;
     const int kp4 = Kp >> 2;
@@ -54,38 +59,64 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     const float* xs0 = Xs + r16 * Kp + 4 * kq;
     const float* xs1 = xs0 + 16 * Kp;
 
-    for (int blk = b_begin + wave; blk < b_end; blk += SK_WAVES) {
+    constexpr int SLOTS = SK_WAVES / KS;  // blocks in flight per workgroup
+    const int slot = wave / KS, kpart = wave % KS;
+    const int gper = (nG + KS - 1) / KS;
+    const int g_lo = kpart * gper, g_hi = min(nG, g_lo + gper);
+    const int iters = (blocks_per_wg + SLOTS - 1) / SLOTS;  // uniform over the workgroup (barriers inside)
+    for (int it = 0; it < iters; ++it) {
+        const int blk = b_begin + it * SLOTS + slot;
+        const bool active = blk < b_end;
         const int n = min(blk * 16 + r16, N - 1);  // clamped rows are computed but never used
         const float* wrow = W + (int64_t)n * ldw + 4 * kq;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 cur[SK_GC], nxt[SK_GC];
-#pragma unroll
-        for (int i = 0; i < SK_GC; ++i) {
-            const bool ok = i < nG && 16 * i + 4 * kq < K;
-            cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        for (int g0 = 0; g0 < nG; g0 += SK_GC) {
+        if (active) {
+            f32x4 cur[SK_GC], nxt[SK_GC];
 #pragma unroll
             for (int i = 0; i < SK_GC; ++i) {
-                const int g = g0 + SK_GC + i;
-                const bool ok = g < nG && 16 * g + 4 * kq < K;
-                nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                const int g = g_lo + i;
+                const bool ok = g < g_hi && 16 * g + 4 * kq < K;
+                cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
+            for (int g0 = g_lo; g0 < g_hi; g0 += SK_GC) {
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) {
-                if (g0 + i < nG) {
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
+                for (int i = 0; i < SK_GC; ++i) {
+                    const int g = g0 + SK_GC + i;
+                    const bool ok = g < g_hi && 16 * g + 4 * kq < K;
+                    nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x0[j], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x1[j], acc1, 0, 0, 0);
+                for (int i = 0; i < SK_GC; ++i) {
+                    if (g0 + i < g_hi) {
+                        const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
+                        const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x0[j], acc0, 0, 0, 0);
+                            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x1[j], acc1, 0, 0, 0);
+                        }
                     }
                 }
-            }
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+                for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+            }
         }
+        if (KS > 1) {
+            // sum the k ranges: every wave leaves its partial, the first wave of the slot adds them up
+            *reinterpret_cast<f32x4*>(&part[wave][0][lane][0]) = acc0;
+            *reinterpret_cast<f32x4*>(&part[wave][1][lane][0]) = acc1;
+            __syncthreads();
+            if (kpart == 0) {
+#pragma unroll
+                for (int q = 1; q < KS; ++q) {
+                    acc0 += *reinterpret_cast<const f32x4*>(&part[wave + q][0][lane][0]);
+                    acc1 += *reinterpret_cast<const f32x4*>(&part[wave + q][1][lane][0]);
+                }
+            }
+            __syncthreads();
+            if (kpart != 0) continue;
+        }
+        if (!active) continue;
         // lane holds columns nb..nb+3 of activation rows (m0 + r16) and (m0 + 16 + r16)
         const int nb = blk * 16 + 4 * kq;
         float bv[4];
@@ -168,16 +199,16 @@ bool sk_ok(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, i
     return SK_ROWS * padded_k(K1 + K2) * 4 <= SK_LDS_BUDGET;
 }
 
-template <bool ARGMAX>
+template <bool ARGMAX, int KS>
 int sk_launch(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2, const float* W,
               int64_t ldw, const float* bias, int M, int N, int bpw, int n_wg, float* C, int64_t ldc, float* pm,
               float* ps, int64_t* pa, hipStream_t s) {
     const int Kp = padded_k(K1 + K2);
     const int lds = SK_ROWS * Kp * 4;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<ARGMAX>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<ARGMAX, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int cvec = C && aligned16(C) && (ldc % 4) == 0;
-    hipLaunchKernelGGL(skinny_kernel<ARGMAX>, dim3(n_wg, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds, s, X1,
+    hipLaunchKernelGGL((skinny_kernel<ARGMAX, KS>), dim3(n_wg, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds, s, X1,
                        ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, Kp, bpw, C, ldc, cvec, pm, ps, pa, n_wg);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
@@ -214,8 +245,9 @@ extern "C" int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const 
         return DSSVAE_EINVAL;
     if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
     const int NB = (N + 15) / 16;
-    return sk_launch<false>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, SK_WAVES, (NB + SK_WAVES - 1) / SK_WAVES, C,
-                            ldc, nullptr, nullptr, nullptr, (hipStream_t)stream);
+    constexpr int KS = 4, BPW = SK_WAVES / KS;
+    return sk_launch<false, KS>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, BPW, (NB + BPW - 1) / BPW, C, ldc,
+                                nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
@@ -226,6 +258,6 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
         return DSSVAE_EINVAL;
     if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
     const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
-    return sk_launch<true>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
+    return sk_launch<true, 1>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
                            part_max, part_sum, part_arg, (hipStream_t)stream);
 }
