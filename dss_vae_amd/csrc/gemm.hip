@@ -195,35 +195,39 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
     sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K);
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
+    // Rotated software pipeline.  Per k-tile: NG groups of 8 k (4 MFMAs per 32x32 tile each); the
+    // fragments of group g+1 are read from LDS while group g multiplies.  The staged registers of tile
+    // kt+1 are written to the other LDS buffer and the barrier is passed BEFORE the last group of tile kt
+    // multiplies, and the first fragments of tile kt+1 are fetched right behind the barrier: the barrier
+    // skew and the LDS latency at the tile boundary hide behind that last group's MFMAs instead of
+    // draining the matrix pipe.  Global loads run a whole k-tile ahead of their LDS stores.
+    constexpr int NG = BK / 8;
     sa.load(kt0 * BK);
     sb.load(kt0 * BK);
     sa.store(As);
     sb.store(Bs);
+    if (kt0 + 1 < kt1) {
+        sa.load((kt0 + 1) * BK);
+        sb.load((kt0 + 1) * BK);
+    }
     __syncthreads();
+    float fa[2][WM][4], fb[2][WN][4];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[0][i], As, arow + 32 * i, 0, h);
+#pragma unroll
+    for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[0][j], Bs, brow + 32 * j, 0, h);
     for (int kt = kt0; kt < kt1; ++kt) {
         const int cur = (kt - kt0) & 1;
         const bool more = kt + 1 < kt1;
-        if (more) {
-            sa.load((kt + 1) * BK);
-            sb.load((kt + 1) * BK);
-        }
         const float* Ab = As + cur * AF;
         const float* Bb = Bs + cur * BF;
-        // fragments of group g+1 are fetched while group g multiplies (explicit register double buffer)
-        float fa[2][WM][4], fb[2][WN][4];
 #pragma unroll
-        for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[0][i], Ab, arow + 32 * i, 0, h);
-#pragma unroll
-        for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[0][j], Bb, brow + 32 * j, 0, h);
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
+        for (int g = 0; g < NG - 1; ++g) {
             const int c = g & 1, n = c ^ 1;
-            if (g + 1 < BK / 8) {
 #pragma unroll
-                for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
+            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
 #pragma unroll
-                for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
-            }
+            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
@@ -231,17 +235,37 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
-            // scheduling order inside the group: the next group's LDS reads first, then this group's MFMAs
-            if (g + 1 < BK / 8) __builtin_amdgcn_sched_group_barrier(0x100, WM * (TA ? 4 : 1) + WN * (TB ? 4 : 1), 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: reads of g+1, then MFMAs of g
         }
-        __builtin_amdgcn_sched_barrier(0);  // keep the staged registers untouched (no vmcnt wait) until here
         if (more) {
             sa.store(As + (cur ^ 1) * AF);
             sb.store(Bs + (cur ^ 1) * BF);
+            if (kt + 2 < kt1) {
+                sa.load((kt + 2) * BK);
+                sb.load((kt + 2) * BK);
+            }
         }
         __syncthreads();
+        constexpr int cl = (NG - 1) & 1, nl = cl ^ 1;  // NG is even: the next tile's group 0 lands in slot 0
+        static_assert(nl == 0, "fragment slot rotation assumes an even number of groups per k-tile");
+        if (more) {
+            const float* An = As + (cur ^ 1) * AF;
+            const float* Bn = Bs + (cur ^ 1) * BF;
+#pragma unroll
+            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[nl][i], An, arow + 32 * i, 0, h);
+#pragma unroll
+            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[nl][j], Bn, brow + 32 * j, 0, h);
+        }
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cl][i][jj], fb[cl][j][jj], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
+    // every wave's LDS reads completed before the last barrier: the buffers are free for the epilogue
 }
 
 // accumulator element (mt, nt, r) of this lane -> tile-local (row, col)

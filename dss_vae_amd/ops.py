@@ -298,9 +298,24 @@ def _col_chunks(M, N):
     return nc
 
 
-def _row_chunks(M, ldd):
-    """rows per chunk so that a [rows, ldd] logits slab fits SLAB_BYTES (whole 128-row tiles, balanced)"""
-    mc_max = max(128, (SLAB_BYTES // (4 * ldd)) // 128 * 128)
+# Row chunks of the fused CE can alternate between several streams (each with its own slab): +4 % on the
+# step at 2 streams, but concurrent kernels blur the per-kernel durations the roofline report is built on,
+# so the default stays at one stream.
+CE_STREAMS = max(1, int(_os.environ.get("DSSVAE_CE_STREAMS", "1")))
+_SIDE = {}
+
+
+def _side_stream(dev, i=0):
+    key = (torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device(), i)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+def _row_chunks(M, ldd, slab_bytes=None):
+    """rows per chunk so that a [rows, ldd] logits slab fits slab_bytes (whole 128-row tiles, balanced)"""
+    slab_bytes = SLAB_BYTES if slab_bytes is None else slab_bytes
+    mc_max = max(128, (slab_bytes // (4 * ldd)) // 128 * 128)
     n_chunks = (M + mc_max - 1) // mc_max
     return ((M + n_chunks - 1) // n_chunks + 127) // 128 * 128
 
@@ -347,8 +362,14 @@ class _LinearCEFn(Function):
             lse, _ = _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N)
         else:
             ldd = (N + 3) // 4 * 4
-            mc = _row_chunks(M, ldd)
-            slab = torch.empty(min(mc, M), ldd, device=dev, dtype=torch.float32)
+            # Row chunks alternate between two streams, each with its own cache-sized slab, so two
+            # chunks are in flight at once: the tail of one kernel (the last, partly filled wave of
+            # workgroups) is filled by the other chain's kernel.  The only cross-chunk dependency is
+            # the accumulation into dW, ordered by events.
+            n_str = CE_STREAMS if (M * ldd * 4 > SLAB_BYTES // CE_STREAMS) else 1
+            mc = _row_chunks(M, ldd, SLAB_BYTES // n_str)
+            n_str = min(n_str, (M + mc - 1) // mc)
+            slabs = [torch.empty(min(mc, M), ldd, device=dev, dtype=torch.float32) for _ in range(n_str)]
             lse = torch.empty(M, device=dev, dtype=torch.float32)
             need_x = need_xh or need_xe
             dx = torch.empty(M, K, device=dev, dtype=torch.float32) if need_x else None
@@ -358,21 +379,35 @@ class _LinearCEFn(Function):
             xcat = None
             if need_w:
                 xcat = xh if xe is None else torch.cat((xh, xe), dim=1)
-            for m0 in range(0, M, mc):
+            main = torch.cuda.current_stream()
+            streams = [main] + [_side_stream(dev, i) for i in range(n_str - 1)]
+            for st in streams[1:]:
+                st.wait_stream(main)
+            wg_done = None  # event: the previous chunk's wgrad (accumulation into dW) has finished
+            for ci, m0 in enumerate(range(0, M, mc)):
                 rows = min(mc, M - m0)
                 xh_c = xh[m0:m0 + rows]
                 xe_c = None if xe is None else xe[m0:m0 + rows]
-                dl = slab[:rows]
-                _lse(xh_c, ldh, Kh, xe_c, lde, Ke, W, ldw, b, rows, N, logits=dl, lse_out=lse[m0:m0 + rows])
-                L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, N,
-                                                        L.ptr(db), L.stream()), "dssvae_softmax_grad_inplace")
-                L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(ones[m0:]),
-                                              rows, 0, N, L.ptr(db), L.stream()), "dssvae_onehot_sub")
-                dlv = dl[:, :N]
-                if need_x:
-                    mm_nn(dlv, W, out=dx[m0:m0 + rows])
-                if need_w:
-                    mm_tn(dlv, xcat[m0:m0 + rows], out=dW, beta=0.0 if m0 == 0 else 1.0)
+                st = streams[ci % n_str]
+                with torch.cuda.stream(st):
+                    dl = slabs[ci % n_str][:rows]
+                    _lse(xh_c, ldh, Kh, xe_c, lde, Ke, W, ldw, b, rows, N, logits=dl, lse_out=lse[m0:m0 + rows])
+                    L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, N,
+                                                            L.ptr(db), L.stream()), "dssvae_softmax_grad_inplace")
+                    L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(ones[m0:]),
+                                                  rows, 0, N, L.ptr(db), L.stream()), "dssvae_onehot_sub")
+                    dlv = dl[:, :N]
+                    if need_x:
+                        mm_nn(dlv, W, out=dx[m0:m0 + rows])
+                    if need_w:
+                        if wg_done is not None and n_str > 1:
+                            st.wait_event(wg_done)
+                        mm_tn(dlv, xcat[m0:m0 + rows], out=dW, beta=0.0 if m0 == 0 else 1.0)
+                        if n_str > 1:
+                            wg_done = torch.cuda.Event()
+                            wg_done.record(st)
+            for st in streams[1:]:
+                main.wait_stream(st)
             ctx.unit_grads = (dx, dW, db)
             ctx.Kh = Kh
         picked = torch.empty(M, T, device=dev, dtype=torch.float32)
