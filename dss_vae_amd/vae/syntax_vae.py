@@ -236,8 +236,13 @@ class SyntaxVAE(TwoEncoderVAE):
         if a.infer_weight > 0.0:
             d.update(adv_syn_inf=0.0, adv_sem_inf=0.0)
         for n, r in zip(names, res):
-            d[n] = -r
+            d[n] = self._head_loss(-r)
         return d, res[len(names):]
+
+    @staticmethod
+    def _head_loss(per_sentence):
+        """SyntaxVAE keeps the tree / sentence heads' per-sentence [B] vector (syntax_vae.py:547-556)"""
+        return per_sentence
 
     def _adv_weights(self, d):
         a = self.args
@@ -262,7 +267,7 @@ class SyntaxVAE(TwoEncoderVAE):
         d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs,
                                          no_grad=self.training)
         adv_syn, adv_sem = self._adv_weights(d)
-        mul_syn = self.args.mul_syn * (-tree)
+        mul_syn = self.args.mul_syn * self._head_loss(-tree)
         mul_sem = self.args.mul_sem * self.sup_sem(sem_h, tgt_var)
         ret["adv"], ret["mul"] = adv_syn + adv_sem, mul_syn + mul_sem
         ret["nll_loss"] = -torch.sum(rec)

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 __all__ = [
     "OVocabEntry", "OVocab", "OExample", "tensorise", "anneal_weight", "word_dropout",
     "ids_to_words", "gru_loop", "bridge_state", "bow_nll", "OracleEncoder", "OracleDecoder",
-    "OracleVanillaVAE", "OracleSyntaxVAE", "OracleEnhanceSyntaxVAE", "ORACLE_MODELS",
+    "OracleVanillaVAE", "OracleSyntaxVAE", "OracleEnhanceSyntaxVAE", "OracleDisentangleVAE", "ORACLE_MODELS",
     "oracle_train_step", "init_uniform_",
 ]
 
@@ -721,8 +721,143 @@ class OracleEnhanceSyntaxVAE(_TwoEncoderBase):
         return self.mul_syn.predict(ret["syn_hidden"])
 
 
+class _BowHeadMean(nn.Module):
+    """DisentangleVAE's BridgeMLP (vae/disentangle_vae.py:570-615): same scorer, but the criterion is
+    nn.NLLLoss(ignore_index=pad) with its default MEAN reduction over all non-pad targets of the batch
+    (:607); with a `stack_mlp` key in args the scorer is Dropout-Linear-ReLU-Linear-LogSoftmax (:591-606)."""
+
+    def __init__(self, args, vocab, enc_dim, dec_dim):
+        super().__init__()
+        self.bridger = _Bridger(args.mapper_type, enc_dim, args.enc_num_layers, dec_dim, args.dec_num_layers)
+        if "stack_mlp" not in args:
+            self.scorer = nn.Sequential(nn.Dropout(args.dec_rd),
+                                        nn.Linear(dec_dim * args.dec_num_layers, len(vocab.src)),
+                                        nn.LogSoftmax(dim=-1))
+        else:
+            self.scorer = nn.Sequential(nn.Dropout(args.dec_rd), nn.Linear(dec_dim * args.dec_num_layers, dec_dim),
+                                        nn.ReLU(), nn.Linear(dec_dim, len(vocab.src)), nn.LogSoftmax(dim=-1))
+        self.pad_id = vocab.src.pad_id
+
+    def forward(self, hidden, tgt):
+        B = tgt.size(0)
+        feat = self.bridger(hidden).permute(1, 0, 2).contiguous().view(B, -1)
+        return bow_nll(self.scorer(feat), tgt, self.pad_id).sum() / tgt.ne(self.pad_id).sum().to(torch.float32)
+
+
+class OracleDisentangleVAE(_TwoEncoderBase):
+    """DisentangleVAE (vae/disentangle_vae.py:33-500) with the int() fix of its latent_for_init (:427; the
+    fixed twin is vae/syntax_vae.py:428): ONE bi-GRU encoder of full width whose per-(layer, direction)
+    final state is cut in halves, first half semantic, second syntactic (:400-404); latent heads with a
+    shared Linear+ReLU trunk when args has a `report` key (:97-121); scalar head losses (:546-554); BoW
+    heads with mean reduction; adversaries under no_grad in train mode (:320-322)."""
+
+    def __init__(self, args, vocab):
+        _OracleBase.__init__(self, args, vocab)
+        self.src_embed = nn.Embedding(len(vocab.src), args.embed_size)
+        self.tgt_embed = nn.Embedding(len(vocab.tgt), args.embed_size)
+        self.latent_size = int(args.latent_size)
+        dirs = 2 if args.bidirectional else 1
+        self.enc_hidden_dim = args.enc_hidden_dim
+        self.enc_layer_dim = args.enc_hidden_dim * dirs
+        self.enc_hidden_factor = dirs * args.enc_num_layers
+        args.use_attention = False
+        self.dec_layer_dim = self.enc_layer_dim if args.mapper_type == "link" else args.dec_hidden_dim
+        var_dim = int(self.enc_hidden_dim * self.enc_hidden_factor / 2)
+        te, td = int(self.enc_layer_dim / 2), int(self.dec_layer_dim / 2)
+        self.encoder = OracleEncoder(len(vocab.src), args.enc_embed_dim, self.enc_hidden_dim, args.enc_num_layers,
+                                     args.bidirectional, args.enc_ed, args.enc_rd, embedding=self.src_embed)
+        main = _SeqHead(args, vocab, self.enc_layer_dim, self.dec_layer_dim,
+                        self.src_embed if args.share_embed else None, "src")
+        self.bridger, self.decoder = main.bridger, main.decoder
+        Z = self.latent_size
+        if "report" in args:
+            syn_common = nn.Sequential(nn.Linear(var_dim, 2 * Z), nn.ReLU())
+            self.syn_mean = nn.Sequential(syn_common, nn.Linear(2 * Z, Z))
+            self.syn_logv = nn.Sequential(syn_common, nn.Linear(2 * Z, Z))
+            sem_common = nn.Sequential(nn.Linear(var_dim, 2 * Z), nn.ReLU())
+            self.sem_mean = nn.Sequential(sem_common, nn.Linear(2 * Z, Z))
+            self.sem_logv = nn.Sequential(sem_common, nn.Linear(2 * Z, Z))
+        else:
+            self.syn_mean, self.syn_logv = nn.Linear(var_dim, Z), nn.Linear(var_dim, Z)
+            self.sem_mean, self.sem_logv = nn.Linear(var_dim, Z), nn.Linear(var_dim, Z)
+        self.syn_to_h = nn.Linear(Z, var_dim)
+        self.sem_to_h = nn.Linear(Z, var_dim)
+        self.sup_syn = _SeqHead(args, vocab, te, td, None, "tgt")
+        self.sup_sem = _BowHeadMean(args, vocab, te, td)
+        self.syn_adv = _SeqHead(args, vocab, te, td, self.tgt_embed if args.share_embed else None, "tgt")
+        self.syn_infer = _SeqHead(args, vocab, te, td, self.src_embed if args.share_embed else None, "src")
+        self.sem_adv = _BowHeadMean(args, vocab, te, td)
+        self.sem_infer = _SeqHead(args, vocab, te, td, self.src_embed if args.share_embed else None, "src")
+
+    def encode(self, ids, lens):
+        if self.training and self.args.src_wd > 0.0:
+            ids = word_dropout(ids, self.step_unk_rate, self.vocab.src, self.noise.get("rand_src"))
+        return self.encoder(ids, lens)
+
+    def hidden_to_latent(self, ret, is_sampling=True):
+        hid = ret["hidden"]  # [layers*dirs, B, H]
+        B, F_ = hid.size(1), hid.size(0)
+        cut = hid.permute(1, 0, 2).contiguous().view(B, F_, 2, -1)
+        sem_h, syn_h = cut[:, :, 0, :].contiguous().view(B, -1), cut[:, :, 1, :].contiguous().view(B, -1)
+        ret["sem_mean"], ret["sem_logv"] = self.sem_mean(sem_h), self.sem_logv(sem_h)
+        ret["syn_mean"], ret["syn_logv"] = self.syn_mean(syn_h), self.syn_logv(syn_h)
+        if is_sampling:  # syntax eps first (:413-414)
+            e_syn = self._draw("eps_syn", [B, self.latent_size])
+            e_sem = self._draw("eps_sem", [B, self.latent_size])
+            ret["syn_z"] = e_syn * torch.exp(0.5 * ret["syn_logv"]) + ret["syn_mean"]
+            ret["sem_z"] = e_sem * torch.exp(0.5 * ret["sem_logv"]) + ret["sem_mean"]
+        else:
+            ret["syn_z"], ret["sem_z"] = ret["syn_mean"], ret["sem_mean"]
+        return ret
+
+    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt):
+        a = self.args
+        d = {"adv_syn_sup": self.syn_adv.neg_logp(sem_h, syn_tgt).sum(), "adv_sem_sup": self.sem_adv(syn_h, sem_tgt)}
+        if a.infer_weight > 0.0:
+            d = {"adv_syn_sup": d["adv_syn_sup"] if a.adv_syn > 0.0 else 0.0,
+                 "adv_sem_sup": d["adv_sem_sup"] if a.adv_sem > 0.0 else 0.0,
+                 "adv_syn_inf": self.syn_infer.neg_logp(syn_h, sem_tgt).sum() if a.inf_syn > 0.0 else 0.0,
+                 "adv_sem_inf": self.sem_infer.neg_logp(sem_h, sem_tgt).sum() if a.inf_sem > 0.0 else 0.0}
+        return d
+
+    def get_loss(self, examples, step, is_dis=False, **_):
+        a = self.args
+        self.step_unk_rate = self.unk_rate * anneal_weight(a.unk_schedule, step, a.k, a.x0)
+        examples, tgt, syn, ret = self._front(examples)
+        B = len(examples)
+        syn_h, sem_h = ret["syn_hidden"], ret["sem_hidden"]
+        if is_dis:
+            d = self._dis_terms(syn_h.detach(), sem_h.detach(), syn, tgt)
+            if a.infer_weight > 0.0:
+                ret["dis syn"] = d["adv_syn_sup"] + d["adv_sem_inf"]
+                ret["dis sem"] = d["adv_sem_sup"] + d["adv_syn_inf"]
+            else:
+                ret["dis syn"], ret["dis sem"] = d["adv_syn_sup"], d["adv_sem_sup"]
+            return ret
+        nll = torch.sum(self._reconstruct(ret, tgt))
+        mul = a.mul_syn * self.sup_syn.neg_logp(syn_h, syn).sum() + a.mul_sem * self.sup_sem(sem_h, tgt)
+        with torch.set_grad_enabled(torch.is_grad_enabled() and not self.training):
+            d = self._dis_terms(syn_h, sem_h, syn, tgt)
+        if a.infer_weight > 0.0:
+            adv = (a.adv_syn * d["adv_syn_sup"] + a.infer_weight * a.inf_sem * d["adv_sem_inf"]
+                   + a.adv_sem * d["adv_sem_sup"] + a.infer_weight * a.inf_syn * d["adv_syn_inf"])
+        else:
+            adv = a.adv_syn * d["adv_syn_sup"] + a.adv_sem * d["adv_sem_sup"]
+        sem_kl, syn_kl, kl, w = self._kl_terms(ret, step)
+        kl, mul, adv, nll = kl / B, mul / B, adv / B, nll / B
+        item = kl * w
+        return {"KL Loss": kl, "NLL Loss": nll, "MUL Loss": mul, "ADV Loss": adv, "KL Weight": w,
+                "KL Item": item, "Model Score": kl + nll, "ELBO": item + nll,
+                "Loss": item + nll + mul - adv, "SYN KL Loss": syn_kl / B, "SEM KL Loss": sem_kl / B}
+
+    def syntax_tokens(self, examples):
+        """eval_syntax (vae/disentangle_vae.py:465-469): greedy tree decode through sup_syn."""
+        ret = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(examples, need_sort=True), False))
+        return self.sup_syn.predict(ret["syn_hidden"])
+
+
 ORACLE_MODELS = {"VanillaVAE": OracleVanillaVAE, "SyntaxVAE": OracleSyntaxVAE,
-                 "SyntaxVAE2": OracleEnhanceSyntaxVAE}
+                 "SyntaxVAE2": OracleEnhanceSyntaxVAE, "DisentangleVAE": OracleDisentangleVAE}
 
 
 def init_uniform_(model, seed=0, bound=0.08):

@@ -24,7 +24,7 @@ def golden_args(g):
 
 
 CASES = ["SyntaxVAE2_tiny", "SyntaxVAE2_mid", "SyntaxVAE_tiny", "SyntaxVAE_mid", "VanillaVAE_tiny",
-         "VanillaVAE_mid"]
+         "VanillaVAE_mid", "DisentangleVAE_tiny", "DisentangleVAE_mid", "DisentangleVAE_plain"]
 
 
 @pytest.fixture(params=CASES)

@@ -67,7 +67,7 @@ def test_golden_eval_losses_and_greedy_decodes(case):
             assert [r[0][0] for r in pm.conditional_generating("sem-only", exs)["res"]] == g["cond_semonly_words"]
         pm.noise = {}
         ex2 = product_examples(examples(g, "examples2"))
-        if g["model"] == "SyntaxVAE2":
+        if g["model"] in ("SyntaxVAE2", "DisentangleVAE"):
             adv = pm.eval_adv(exs, ex2)
             assert [r[0][0] for r in adv["res"]] == g["transfer_words"]
             assert [r[0][0] for r in adv["ori syn"]] == g["transfer_ori_syn"]
@@ -136,12 +136,12 @@ def test_golden_three_optimisation_steps(case):
 
 
 @pytest.mark.parametrize("model,fixed", [("SyntaxVAE2", True), ("SyntaxVAE2", False), ("SyntaxVAE", False),
-                                         ("VanillaVAE", False)])
+                                         ("VanillaVAE", False), ("DisentangleVAE", False)])
 def test_oracle_parity_default_dims(model, fixed):
     """default dims of configs/model_configs/syntax-vae*.yaml (E=H=300 -> h=150, D=600, tau=300, Z=100:
     none a multiple of 128) at V=2000, B=24: losses, grad-norm, greedy decode vs the CPU oracle."""
     n_src, n_tgt, B = 2000, 104, 24
-    args = make_args(dec_ed=0.0, dec_rd=0.0, tgt_wd=model != "VanillaVAE")
+    args = make_args(dec_ed=0.0, dec_rd=0.0, tgt_wd=model not in ("VanillaVAE", "DisentangleVAE"))
     om, pm = build_pair(model, args, n_src, n_tgt, seed=1, train=True)
     exs = make_examples(B, n_src, n_tgt, src_len=30, tree_len=90, fixed=fixed, seed=11)
     gen = torch.Generator().manual_seed(5)

@@ -110,12 +110,13 @@ def test_eval_losses_and_decodes(case):
             m.noise = {"eps_syn": e[0], "eps_sem": e[1], "eps_syn_prior": e[2]}
             assert words(m.conditional_generating("sem-only", exs), m.vocab.src) == g["cond_semonly_words"]
         m.noise = {}
-        if g["model"] == "SyntaxVAE2":
+        if g["model"] in ("SyntaxVAE2", "DisentangleVAE"):
             ex2 = examples(g, "examples2")
             toks, a, b = m.transfer_tokens(exs, ex2)
+            head = m.mul_syn if g["model"] == "SyntaxVAE2" else m.sup_syn
             assert words(toks, m.vocab.src) == g["transfer_words"]
-            assert words(m.mul_syn.predict(a["syn_hidden"]), m.vocab.tgt) == g["transfer_ori_syn"]
-            assert words(m.mul_syn.predict(b["syn_hidden"]), m.vocab.tgt) == g["transfer_ref_syn"]
+            assert words(head.predict(a["syn_hidden"]), m.vocab.tgt) == g["transfer_ori_syn"]
+            assert words(head.predict(b["syn_hidden"]), m.vocab.tgt) == g["transfer_ref_syn"]
             assert words(m.syntax_tokens(ex2), m.vocab.tgt) == g["eval_syntax_words"]
 
 
@@ -167,6 +168,6 @@ def test_three_optimisation_steps(case):
     sd = m.state_dict()
     for k, v in g["steps_final_state"].items():
         # Adam's first steps are ~lr*sign(g): where g ~ 0 rounding noise is amplified; lr = 5e-4
-        close(sd[k], v, rtol=1e-5, atol=5e-6, what="final " + k)
+        close(sd[k], v, rtol=1e-5, atol=1e-5, what="final " + k)
     for n, p in m.named_parameters():
         assert bool(p.requires_grad) == g["steps_requires_grad"][n], n
