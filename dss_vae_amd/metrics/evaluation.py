@@ -1,0 +1,85 @@
+"""Decode-and-score glue (reference: dss_vae/metrics/evaluation.py:19-125, metrics/tools.py:17-164):
+batches sorted by -len, model.predict per batch (greedy decode on the MI355X), input/pred/gold text
+files, corpus BLEU."""
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import bleu
+
+
+def write_result(docs, fname):
+    with open(fname, "w") as f:
+        if isinstance(docs, list):
+            for doc in docs:
+                f.write(" ".join(doc) if isinstance(doc, list) else doc)
+                f.write("\n")
+        elif isinstance(docs, dict):
+            for key, val in docs.items():
+                if val is not None:
+                    f.write("%s:%f" % (key, torch.mean(val) if isinstance(val, torch.Tensor) else val))
+                    f.write("\n")
+
+
+def predict_to_plain(decode_results):
+    return [" ".join(hyp[0][0]) for hyp in decode_results]
+
+
+def prepare_ref(examples, eval_tgt, vocab):
+    return [[[e.src]] for e in examples] if eval_tgt == "src" else [[[e.tgt]] for e in examples]
+
+
+def batchify_examples(examples, sort_key="src", batch_size=None, sort=True):
+    if batch_size is None:
+        batch_size = 50 if len(examples) > 50 else len(examples)
+    if sort:
+        origin_ids = sorted(range(len(examples)), key=lambda i: -len(getattr(examples[i], sort_key)))
+    else:
+        origin_ids = np.arange(len(examples))
+    examples = sorted(examples, key=lambda e: -len(getattr(e, sort_key)))
+    return [examples[i:i + batch_size] for i in range(0, len(examples), batch_size)], origin_ids
+
+
+def decode(examples, model):
+    was_training = model.training
+    model.eval()
+    with torch.no_grad():
+        res = model.predict(examples)
+    if was_training:
+        model.train()
+    return res
+
+
+def prediction(examples, model, sort_key="src", eval_src="src", out_dir=None, batch_size=None):
+    if batch_size is None:
+        batch_size = 50 if "eval_bs" not in model.args else model.args.eval_bs
+    batches, ids = batchify_examples(examples, sort_key=sort_key, batch_size=batch_size)
+    t0 = time.time()
+    cache = []
+    for b in batches:
+        cache.extend(decode(b, model))
+    use_time = time.time() - t0
+    pred = [None] * len(cache)
+    for new_id, ori in enumerate(ids):
+        pred[ori] = cache[new_id]
+    out_dir = "./" if out_dir is None else out_dir
+    if not os.path.exists(out_dir):
+        os.makedirs(out_dir)
+    res = {"predict": pred, "oracle_accuracy": 0.0, "use_time": use_time,
+           "input_file": os.path.join(out_dir, "input.txt"), "pred_file": os.path.join(out_dir, "pred.txt")}
+    write_result(predict_to_plain(prepare_ref(examples, eval_src, model.vocab)), res["input_file"])
+    write_result(predict_to_plain(pred), res["pred_file"])
+    return res
+
+
+def new_evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", ret_dec_result=False, batch_size=None,
+                 out_dir=None):
+    res = prediction(examples, model, sort_key, eval_src, out_dir, batch_size)
+    res["reference"] = prepare_ref(examples, eval_tgt, model.vocab)
+    out_dir = "./" if out_dir is None else out_dir
+    res["gold_file"] = os.path.join(out_dir, "gold.txt")
+    write_result(predict_to_plain(res["reference"]), res["gold_file"])
+    res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    return (res, res["predict"]) if ret_dec_result else res

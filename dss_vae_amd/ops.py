@@ -148,6 +148,9 @@ class _LinearFn(Function):
     @staticmethod
     def forward(ctx, x, w, b):
         L.require_cuda(x, w)
+        # an output that receives no gradient must leave the inputs' gradients undefined (None), not zero:
+        # torch.optim.Adam semantics (a parameter without a gradient is skipped) depend on it
+        ctx.set_materialize_grads(False)
         x2 = x.reshape(-1, x.size(-1))
         ctx.save_for_backward(x2, w)
         ctx.has_bias = b is not None
@@ -156,6 +159,8 @@ class _LinearFn(Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.size(-1)).contiguous()
         dx = mm_nn(dy2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
@@ -175,6 +180,7 @@ class _EmbedFn(Function):
     @staticmethod
     def forward(ctx, table, ids, mask):
         L.require_cuda(table, ids)
+        ctx.set_materialize_grads(False)
         flat = ids.reshape(-1).contiguous()
         M, E = flat.numel(), table.size(1)
         out = torch.empty(M, E, device=table.device, dtype=torch.float32)
@@ -187,7 +193,7 @@ class _EmbedFn(Function):
     @staticmethod
     def backward(ctx, g):
         flat, mask = ctx.saved_tensors
-        if not ctx.needs_input_grad[0]:
+        if g is None or not ctx.needs_input_grad[0]:
             return None, None, None
         V, E = ctx.tshape
         g2 = g.reshape(-1, E).contiguous()
@@ -230,6 +236,7 @@ class _ReparamKLFn(Function):
     @staticmethod
     def forward(ctx, mean, logv, eps):
         L.require_cuda(mean, logv)
+        ctx.set_materialize_grads(False)
         mean, logv = mean.contiguous(), logv.contiguous()
         eps = None if eps is None else eps.contiguous()
         z = torch.empty_like(mean)
@@ -242,6 +249,8 @@ class _ReparamKLFn(Function):
     @staticmethod
     def backward(ctx, dz, dkl):
         mean, logv, eps = ctx.saved_tensors
+        if dz is None and dkl is None:
+            return None, None, None
         dz = None if dz is None else dz.contiguous()
         dkl = None if dkl is None else dkl.contiguous()
         dm, dv = torch.empty_like(mean), torch.empty_like(logv)
@@ -337,6 +346,7 @@ class _LinearCEFn(Function):
     @staticmethod
     def forward(ctx, xh, xe, W, b, target, ignore_index, uniform):
         L.require_cuda(xh, W, target)
+        ctx.set_materialize_grads(False)
         xh, ldh = _rows(_f32(xh))
         Kh = xh.size(1)
         if xe is not None:
@@ -420,6 +430,9 @@ class _LinearCEFn(Function):
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            ctx.unit_grads = None
+            return None, None, None, None, None, None, None
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         if ctx.fused:
             # every row has the same upstream gradient (the caller's contract): scale the unit gradients

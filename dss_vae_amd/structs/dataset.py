@@ -33,8 +33,13 @@ class Dataset(object):
 
     @staticmethod
     def from_bin_file(file_path):
-        with open(file_path, "rb") as f:
-            return Dataset(pickle.load(f))
+        from .io import load_bin
+        return Dataset(load_bin(file_path))
+
+    def save(self, file_path):
+        """a pickled LIST of examples, as structs/generate_dataset.py:146-157 writes it"""
+        from .io import dump_bin
+        dump_bin(list(self.examples), file_path)
 
     @staticmethod
     def from_list(raw_list):

@@ -63,5 +63,9 @@ class Vocab(object):
         import os
         if os.path.getsize(file_path) <= 0:
             raise RuntimeWarning("Empty vocab")
-        with open(file_path, "rb") as f:
-            return pickle.load(f)
+        from .io import load_bin
+        return load_bin(file_path)
+
+    def save(self, file_path):
+        from .io import dump_bin
+        dump_bin(self, file_path)

@@ -30,7 +30,14 @@ def build_model_params_(model, seed=None, bound=0.08):
 
 
 class FlatAdam(object):
-    """Adam + clip_grad_norm_ over flat parameter / gradient buffers, optionally data-parallel."""
+    """Adam + clip_grad_norm_ over flat parameter / gradient buffers, optionally data-parallel.
+
+    torch.optim.Adam semantics are kept where the reference's loop depends on them: a parameter that
+    received NO gradient in a step (the frozen adversaries in the main pass, everything but the
+    adversaries in a discriminator pass) is skipped entirely -- no moment decay, no update, and its own
+    step count (Adam's bias correction is per parameter) does not advance.  Which parameters received a
+    gradient is recorded by tensor hooks; the update then runs over the contiguous ranges of
+    the flat buffer that are live (a handful of launches)."""
 
     def __init__(self, model, lr=0.0005, betas=(0.9, 0.995), eps=1e-8, clip_grad=5.0, bucket_mb=64,
                  process_group=None, data_parallel=True):
@@ -44,35 +51,54 @@ class FlatAdam(object):
         self.grad = torch.zeros(total, device=dev)
         self.m = torch.zeros(total, device=dev)
         self.v = torch.zeros(total, device=dev)
-        off = 0
+        self.offsets, off = [], 0
         for p, n in zip(params, sizes):
             view = self.flat[off:off + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            self.offsets.append(off)
             off += n
-        self.params, self.lr, self.betas, self.eps, self.clip = params, lr, betas, eps, clip_grad
-        self.t = 0
+        self.sizes = sizes
+        self.params, self.betas, self.eps, self.clip = params, betas, eps, clip_grad
+        self.param_groups = [{"lr": lr}]  # the reference's lr decay writes optimizer.param_groups[0]['lr']
+        self.steps = [0] * len(params)    # Adam's per-parameter step count
+        self.fired = set()
         self.sumsq = torch.zeros(1, device=dev)
         self.world = world_size(process_group) if data_parallel else 1
         self.buckets = None
         force = os.environ.get("DSSVAE_DP_FORCE", "0") == "1" and data_parallel and world_size(process_group) == 1 \
             and torch.distributed.is_initialized()
         if self.world > 1 or force:  # force: rehearse the whole DP schedule on a 1-rank group
-            offsets, o = [], 0
-            for n in sizes:
-                offsets.append(o)
-                o += n
             overlap = os.environ.get("DSSVAE_DP_OVERLAP", "1") != "0"
-            self.buckets = GradBuckets(self.grad, params, offsets, max(1, int(bucket_mb * (1 << 20) // 4)),
+            self.buckets = GradBuckets(self.grad, params, self.offsets, max(1, int(bucket_mb * (1 << 20) // 4)),
                                        group=process_group, overlap=overlap)
-            for i, p in enumerate(params):
+        for i, p in enumerate(params):
+            # a tensor hook sees the arriving gradient: None when it is undefined (the parameter's consumers
+            # got no gradient this step); a leaf frozen after its use still gets the call but accumulates
+            # nothing.  (A post-accumulate hook fires in all of these cases alike.)
+            p.register_hook(lambda g, i=i: self._on_arrive(i, g))
+            if self.buckets is not None:
                 p.register_post_accumulate_grad_hook(lambda _p, i=i: self.buckets.mark_ready(i))
+
+    @property
+    def lr(self):
+        return self.param_groups[0]["lr"]
+
+    @property
+    def t(self):
+        """number of optimisation steps taken by the most-updated parameter"""
+        return max(self.steps)
+
+    def _on_arrive(self, i, g):
+        if g is not None and self.params[i].requires_grad:
+            self.fired.add(i)
 
     def zero_grad(self, tag="main"):
         """tag: kind of step that follows (steps of one kind share an autograd graph shape; the
         data-parallel bucket schedule is learned per kind)."""
         self.grad.zero_()
+        self.fired = set()
         for p in self.params:  # autograd may have replaced a view (e.g. after requires_grad toggling)
             if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr() or \
                     p.grad.data_ptr() >= self.grad.data_ptr() + self.grad.numel() * 4:
@@ -82,27 +108,49 @@ class FlatAdam(object):
             self.buckets.reset(tag)
 
     def _rebind(self):
-        off = 0
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.grad[off:off + p.numel()].view(p.shape)
-            off += (p.numel() + 3) // 4 * 4
 
     def all_reduce_grads(self):
         """gradient average over RCCL (xGMI): buckets not yet sent by the backward hooks go now."""
         if self.buckets is not None:
             self.buckets.finish()
 
+    def _live_ranges(self):
+        """contiguous [lo, hi) element ranges of parameters that got a gradient, split where the
+        per-parameter step counts differ -> [(lo, hi, step_after_this_update)]"""
+        out = []
+        for i in sorted(self.fired):
+            lo, hi, st = self.offsets[i], self.offsets[i] + self.sizes[i], self.steps[i] + 1
+            if out and out[-1][1] == lo and out[-1][2] == st:
+                out[-1] = (out[-1][0], hi, st)
+            else:
+                out.append((lo, hi, st))
+        return out
+
     def step(self):
         self.all_reduce_grads()
-        self.t += 1
         self.sumsq.zero_()
         ops.sumsq(self.grad, self.sumsq)
-        ops.adam_step(self.flat, self.grad, self.m, self.v, self.lr, self.betas[0], self.betas[1], self.eps, self.t,
-                      self.sumsq if self.clip > 0.0 else None, self.clip)
+        for lo, hi, st in self._live_ranges():
+            ops.adam_step(self.flat[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
+                          self.betas[1], self.eps, st, self.sumsq if self.clip > 0.0 else None, self.clip)
+        for i in self.fired:
+            self.steps[i] += 1
 
     def grad_norm(self):
         """global gradient norm of the LAST step (device sync; for logging / tests)."""
         return float(self.sumsq.sqrt().item())
+
+    # ---- checkpoint (the reference saves optimizer.state_dict() next to model.bin) ---------------
+    def state_dict(self):
+        return {"lr": self.lr, "steps": list(self.steps), "exp_avg": self.m.clone(), "exp_avg_sq": self.v.clone()}
+
+    def load_state_dict(self, sd):
+        self.param_groups[0]["lr"] = sd["lr"]
+        self.steps = list(sd["steps"])
+        self.m.copy_(sd["exp_avg"])
+        self.v.copy_(sd["exp_avg_sq"])
 
 
 def train_step(model, optimizer, examples, train_iter):
