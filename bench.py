@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--model", default="SyntaxVAE2", choices=["SyntaxVAE2", "SyntaxVAE", "VanillaVAE"])
+    ap.add_argument("--model", default="SyntaxVAE2", choices=["SyntaxVAE2", "SyntaxVAE", "VanillaVAE", "DisentangleVAE"])
     ap.add_argument("--batch", type=int, default=256, help="sentences per GPU")
     ap.add_argument("--vocab", type=int, default=30000)
     ap.add_argument("--tree-vocab", type=int, default=300)
@@ -64,6 +64,8 @@ def parse():
     ap.add_argument("--mode", default="train", choices=["train", "generate"],
                     help="train = the headline metric; generate = BASELINE configs[4] (prior sampling + syntax "
                          "transfer greedy decode), a secondary line")
+    ap.add_argument("--adv-train", action="store_true",
+                    help="secondary: the 3-pass adversarial iteration (dis-syn step, dis-sem step, main step)")
     ap.add_argument("--gen-sentences", type=int, default=10000)
     ap.add_argument("--gen-batch", type=int, default=50, help="eval_bs (reference default 50)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -179,11 +181,11 @@ def main():
 
     from dss_vae_amd import ops, synthetic
     from dss_vae_amd.models import MODEL_CLS
-    from dss_vae_amd.train import FlatAdam, build_model_params_, train_step
+    from dss_vae_amd.train import FlatAdam, build_model_params_, train_iteration
     from dss_vae_amd.vae.base_vae import DeviceBatch
 
     over = dict(synthetic.STRESS_OVERRIDES) if a.stress else {}
-    if a.model == "VanillaVAE":
+    if a.model in ("VanillaVAE", "DisentangleVAE"):
         over["tgt_wd"] = False  # the reference's tgt_wd path of VanillaVAE does not run (vanilla_vae.py:112)
     margs = synthetic.model_args(model_select=a.model, task_type=a.model, **over)
     margs_dict = dict(vars(margs))
@@ -209,14 +211,14 @@ def main():
     it = 6000
     for _ in range(a.warmup):
         it += 1
-        train_step(model, opt, batch, it)
+        train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
     sync()
     timer = None if a.no_kernel_events else ops.KernelTimer()
     ops.PROFILE = timer
     t0 = time.perf_counter()
     for _ in range(a.steps):
         it += 1
-        ret = train_step(model, opt, batch, it)
+        ret = train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE = None
@@ -233,9 +235,11 @@ def main():
             "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[%d]: full DSS-VAE (%s) fwd+bwd+clip+Adam, vocab %d, tree vocab %d, "
+            "config": {"workload": "BASELINE configs[%d]: full DSS-VAE (%s) %sfwd+bwd+clip+Adam, vocab %d, tree vocab %d, "
                                    "src len %d, tree len %d%s, batch %d per GPU, E=%d H=%d Z=%d, fp32"
-                                   % (3 if a.stress else 1, a.model, a.vocab, a.tree_vocab, a.src_len, a.tree_len,
+                                   % (3 if a.stress else 1, a.model,
+                                      "3-pass adversarial iteration (dis-syn, dis-sem, main), each " if a.adv_train else "",
+                                      a.vocab, a.tree_vocab, a.src_len, a.tree_len,
                                       " (variable)" if a.variable_lengths else " (fixed)", a.batch, margs.embed_size,
                                       margs.enc_hidden_dim, margs.latent_size),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params": n_params},

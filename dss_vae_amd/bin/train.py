@@ -18,6 +18,7 @@ import torch.distributed as dist
 
 from ..metrics import get_evaluator
 from ..parallel import shard_examples, world_size
+from ..train import train_iteration
 from ..utils.config_funcs import dict_to_args, yaml_to_dict
 from ..utils.model_utils import build_model, get_lr_schedule, get_model_info, load_data, update_tracker
 
@@ -73,12 +74,6 @@ def training(main_args, model_args, model=None, max_iters=None):
         adv_syn = (model_args.adv_syn + model_args.infer_weight * model_args.inf_sem) > 0.0
         adv_sem = (model_args.adv_sem + model_args.infer_weight * model_args.inf_syn) > 0.0
 
-    def dis_pass(key, tag):
-        ret_loss = model.get_loss(examples=batch_examples, train_iter=train_iter, is_dis=True)
-        optimizer.zero_grad(tag)
-        ret_loss[key].backward()
-        optimizer.step()
-
     while True:
         epoch += 1
         epoch_begin = time.time()
@@ -89,16 +84,8 @@ def training(main_args, model_args, model=None, max_iters=None):
                 continue
             train_iter += 1
             train_nums += len(batch_examples)
-            if adv_training:  # universal_training, bin/train.py:90-108
-                if adv_syn:
-                    dis_pass("dis syn", "dis_syn")
-                if adv_sem:
-                    dis_pass("dis sem", "dis_sem")
-            optimizer.zero_grad("main")
-            batch_ret = model.get_loss(examples=batch_examples, return_enc_state=False, train_iter=train_iter)
+            batch_ret = train_iteration(model, optimizer, batch_examples, train_iter, adv_syn, adv_sem)
             batch_loss = batch_ret["Loss"]
-            torch.mean(batch_loss).backward()
-            optimizer.step()  # global-norm clip (clip_grad) + Adam, after the gradient all-reduce
             train_log_dict = update_tracker(batch_ret, train_log_dict)
             if train_iter % main_args.log_every == 0:
                 train_loss += batch_loss.detach().sum().item() * main_args.log_every  # sampled: no per-step sync

@@ -505,7 +505,9 @@ class _LinearCEFn(Function):
 def linear_ce(xh, xe, W, b, target, ignore_index=0, uniform_upstream=False):
     """-> per-row summed NLL [M]; xe may be None; target [M] or [M,T].  uniform_upstream=True: the caller
     guarantees that every row's NLL receives the same upstream gradient (see _LinearCEFn)."""
-    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index, uniform_upstream)
+    # under no_grad nothing will ever ask for gradients: take the forward-only path (inside Function.forward
+    # grad mode is always off and needs_input_grad still mirrors requires_grad, so decide here)
+    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index, bool(uniform_upstream) and torch.is_grad_enabled())
 
 
 def linear_argmax(xh, xe, W, b):

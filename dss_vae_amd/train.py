@@ -153,9 +153,22 @@ class FlatAdam(object):
         self.v.copy_(sd["exp_avg_sq"])
 
 
+def train_iteration(model, optimizer, examples, train_iter, adv_syn=False, adv_sem=False):
+    """universal_training + the main step (bin/train.py:90-126): with `adv_train`, a discriminator step on
+    'dis syn' and one on 'dis sem' (each its own get_loss(is_dis=True) / zero_grad / backward / clip /
+    Adam) precede the main pass."""
+    for key, tag, on in (("dis syn", "dis_syn", adv_syn), ("dis sem", "dis_sem", adv_sem)):
+        if on:
+            ret = model.get_loss(examples=examples, train_iter=train_iter, is_dis=True)
+            optimizer.zero_grad(tag)
+            ret[key].backward()
+            optimizer.step()
+    return train_step(model, optimizer, examples, train_iter)
+
+
 def train_step(model, optimizer, examples, train_iter):
     """one main-pass iteration; returns the loss dict of get_loss."""
-    optimizer.zero_grad()
+    optimizer.zero_grad("main")
     ret = model.get_loss(examples, train_iter)
     torch.mean(ret["Loss"]).backward()
     optimizer.step()
