@@ -222,6 +222,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE = None
+    ops.check_persistent_errors()
     loss = float(torch.mean(ret["Loss"]).item())
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
@@ -264,6 +265,8 @@ def main():
                                 "traffic": traffic.get(name, {}).get("hbm_bytes_per_launch"),
                                 "algorithmic_per_launch": (d["flops"] if bound == "mfma" else d["bytes"]) / d["launches"],
                                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                                "tflops": d["flops"] / (d["total_ms"] * 1e-3) / 1e12,
+                                "us_per_timestep": (1e3 * d["total_ms"] / d["timesteps"]) if d.get("timesteps") else None,
                                 "launches_per_step": d["launches"] / a.steps,
                                 "avg_launch_ms": d["avg_ms"], "ms_per_step": d["total_ms"] / a.steps})
             kernels.sort(key=lambda k: -k["ms_per_step"])

@@ -16,6 +16,7 @@ import time
 import torch
 import torch.distributed as dist
 
+from .. import ops
 from ..metrics import get_evaluator
 from ..parallel import shard_examples, world_size
 from ..train import train_iteration
@@ -88,6 +89,7 @@ def training(main_args, model_args, model=None, max_iters=None):
             batch_loss = batch_ret["Loss"]
             train_log_dict = update_tracker(batch_ret, train_log_dict)
             if train_iter % main_args.log_every == 0:
+                ops.check_persistent_errors()
                 train_loss += batch_loss.detach().sum().item() * main_args.log_every  # sampled: no per-step sync
                 print("\r[Iter %d] Train loss=%.5f" % (train_iter, train_loss / train_nums), file=sys.stdout, end=" ")
                 for key, val in train_log_dict.items():

@@ -16,17 +16,18 @@ class KernelTimer(object):
     average launch duration live; with ``PROFILE = None`` (default) nothing is recorded."""
 
     def __init__(self):
-        self.spans = []  # (kernel name, start event, end event, algorithmic flops, algorithmic bytes)
+        self.spans = []  # (kernel name, start event, end event, algorithmic flops, algorithmic bytes, timesteps)
 
     def summary(self):
         """-> {kernel: dict(launches, total_ms, avg_ms, flops, bytes)}; call after a device sync."""
         out = {}
-        for name, e0, e1, fl, by in self.spans:
-            d = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0))
+        for name, e0, e1, fl, by, st in self.spans:
+            d = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, timesteps=0))
             d["launches"] += 1
             d["total_ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += by
+            d["timesteps"] += st
         for d in out.values():
             d["avg_ms"] = d["total_ms"] / d["launches"]
         return out
@@ -36,10 +37,10 @@ PROFILE = None
 
 
 class _Span(object):
-    __slots__ = ("name", "flops", "bytes", "e0")
+    __slots__ = ("name", "flops", "bytes", "e0", "steps")
 
-    def __init__(self, name, flops, nbytes):
-        self.name, self.flops, self.bytes = name, flops, nbytes
+    def __init__(self, name, flops, nbytes, steps=0):
+        self.name, self.flops, self.bytes, self.steps = name, flops, nbytes, steps
 
     def __enter__(self):
         if PROFILE is not None:
@@ -51,7 +52,7 @@ class _Span(object):
         if PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes)))
+            PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes), int(self.steps)))
         return False
 
 
@@ -609,6 +610,29 @@ def _pack(insts):
     return [sorted(l[0]) for l in launches]
 
 
+_PERSISTENT_ERR = {}
+
+
+def _note_persistent_error(wsb):
+    """fold the launch's error word (first int32 of its workspace: a bounded spin gave up) into a sticky
+    per-device counter, on the stream and without a host sync; `check_persistent_errors` reads it."""
+    key = wsb.device.index
+    if key not in _PERSISTENT_ERR:
+        _PERSISTENT_ERR[key] = torch.zeros(1, device=wsb.device, dtype=torch.int32)
+    _PERSISTENT_ERR[key].add_(wsb[:4].view(torch.int32))
+
+
+def check_persistent_errors():
+    """raise if any persistent GRU launch since the last call timed out waiting for a peer workgroup
+    (its results are then garbage).  One device sync: call it where the loop synchronises anyway."""
+    for key, t in _PERSISTENT_ERR.items():
+        n = int(t.item())
+        if n:
+            t.zero_()
+            raise RuntimeError("%d persistent GRU launch(es) on device %s gave up waiting for a peer workgroup "
+                               "(DSSVAE_ETIMEOUT): the grid was not co-resident" % (n, key))
+
+
 def _workspace(Bs, Hs, dev):
     n = len(Bs)
     nbytes = L.load().dssvae_gru_workspace_bytes(n, (C.c_int32 * n)(*Bs), (C.c_int32 * n)(*Hs))
@@ -675,8 +699,9 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save[i] else 4) for i in launch)
-            with _Span("gru_fwd_kernel", fl, by):
+            with _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch)):
                 L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
+            _note_persistent_error(wsb)
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
@@ -727,8 +752,9 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
-            with _Span("gru_bwd_kernel", fl, by):
+            with _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch)):
                 L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
+            _note_persistent_error(wsb)
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         out = [None]
