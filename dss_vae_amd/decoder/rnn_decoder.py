@@ -167,10 +167,17 @@ def score_many(jobs):
         dec = j["dec"]
         B, T, H = xs[k].shape
         gold = j["targets"][:, 1:].reshape(-1)
+        keep = getattr(j["targets"], "_keep_rows", None)  # ragged batch: rows whose target is not <pad>
         with torch.set_grad_enabled(grad_on and not j.get("no_grad")):
-            nll = ops.linear_ce(xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1), dec.out.weight, dec.out.bias,
-                                gold, dec.pad_id,
-                                uniform_upstream=bool(j.get("uniform")) and not j.get("norm_by_word"))
+            xh, xe = xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1)
+            uni = bool(j.get("uniform")) and not j.get("norm_by_word")
+            if keep is None:
+                nll = ops.linear_ce(xh, xe, dec.out.weight, dec.out.bias, gold, dec.pad_id, uniform_upstream=uni)
+            else:
+                # pad rows add nothing to the loss or to any gradient: leave them out of the projection
+                part = ops.linear_ce(xh.index_select(0, keep), xe.index_select(0, keep), dec.out.weight,
+                                     dec.out.bias, gold.index_select(0, keep), dec.pad_id, uniform_upstream=uni)
+                nll = torch.zeros(B * T, device=part.device, dtype=part.dtype).index_copy(0, keep, part)
             logp = -nll.view(B, T).sum(1)
             if j.get("norm_by_word"):
                 logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())

@@ -11,6 +11,17 @@ from ..networks.rnn_base import GLOBAL_SEEDS
 from ..utils.nn_funcs import device, id2word, kl_anneal_function, to_input_variable, unk_replace
 
 
+def _keep_rows(lengths, T, dev):
+    """Row indices, in the flattened [B, T] layout of a teacher-forced decoder, whose target is not <pad>
+    (targets are ids[:, 1:] of <s> w_1 .. w_L </s> <pad>..: L + 1 real targets per sentence).  None when
+    no row is padding.  Known on the host from the lengths, so a ragged batch costs no device sync; the
+    scoring path projects only these rows onto the vocabulary (decoder/rnn_decoder.py: score_many)."""
+    if all(L + 1 >= T for L in lengths):
+        return None
+    idx = [b * T + t for b, L in enumerate(lengths) for t in range(min(L + 1, T))]
+    return torch.as_tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
+
+
 class DeviceBatch(object):
     """Pre-tensorised minibatch resident in HBM (kills the per-step Python tensorisation of
     utils/nn_funcs.py:143-174).  Accepted wherever a list of examples is."""
@@ -21,10 +32,12 @@ class DeviceBatch(object):
         self.length = [len(w) for w in words]
         self.src = to_input_variable(words, vocab.src, batch_first=True)
         self.tgt_var = to_input_variable(words, vocab.src, append_boundary_sym=True, batch_first=True)
+        self.tgt_var._keep_rows = _keep_rows(self.length, self.tgt_var.size(1) - 1, self.tgt_var.device)
         self.syn_var = None
         if with_tgt and examples[0].tgt is not None:
-            self.syn_var = to_input_variable([e.tgt for e in examples], vocab.tgt, append_boundary_sym=True,
-                                             batch_first=True)
+            trees = [e.tgt for e in examples]
+            self.syn_var = to_input_variable(trees, vocab.tgt, append_boundary_sym=True, batch_first=True)
+            self.syn_var._keep_rows = _keep_rows([len(t) for t in trees], self.syn_var.size(1) - 1, self.syn_var.device)
 
     def __len__(self):
         return len(self.examples)
