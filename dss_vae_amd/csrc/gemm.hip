@@ -369,97 +369,103 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
 }
 
 // ---- LSE (optionally with argmax) ----------------------------------------------------------------
+// Row statistics are taken from the tile's LDS image, not from the accumulators: the image is read
+// back row-major (the same 16-byte pieces that leave for the logits slab), so a thread meets the SAME
+// 16 rows and the same 4 column offsets in every column tile and carries 16 (max, sum[, arg]) triples
+// instead of one per accumulator row (32 per lane): the kernel fits 2 waves per SIMD (two
+// workgroups per CU), which is what hides the epilogue and the barrier skew behind the other
+// workgroup's MFMAs.  One 32-lane shuffle reduction per row at the very end.
 template <bool ARG, bool VEC, bool STORE>
-__global__ __launch_bounds__(NTHREADS) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
-                                                               int N, int K, int n_split, int tiles_per_split,
-                                                               int tiles_n, float* __restrict__ part_max,
-                                                               float* __restrict__ part_sum,
-                                                               int64_t* __restrict__ part_arg,
-                                                               float* __restrict__ logits, int64_t ldl, int lvec) {
+__global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
+                                                                  int N, int K, int n_split, int tiles_per_split,
+                                                                  int tiles_n, float* __restrict__ part_max,
+                                                                  float* __restrict__ part_sum,
+                                                                  int64_t* __restrict__ part_arg,
+                                                                  float* __restrict__ logits, int64_t ldl, int lvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int BM = 128, BN = 128;
+    constexpr int BM = 128, BN = 128, LDT = BN + 4;
+    constexpr int TPR = BN / 4, RPP = NTHREADS / TPR, NR = BM / RPP;  // 32 threads per row, 8 rows per pass, 16 passes
+    static_assert(BM * LDT <= lds_floats<false, false, 2, 2>(), "tile image must fit in the operand buffers");
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
     const int m0 = mb * BM;
     const int t_begin = split * tiles_per_split;
     const int t_end = min(t_begin + tiles_per_split, tiles_n);
     const int nk = (K + BK - 1) / BK;
-    float rm[2][16], rs[2][16];
-    int ra[2][16];
+    const int col = 4 * (threadIdx.x % TPR), rbase = threadIdx.x / TPR;
+    float rm[NR], rs[NR];
+    int ra[ARG ? NR : 1];
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { rm[mt][r] = NEG_BIG; rs[mt][r] = 0.f; ra[mt][r] = 0; }
+    for (int i = 0; i < NR; ++i) { rm[i] = NEG_BIG; rs[i] = 0.f; if (ARG) ra[i] = 0; }
 
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x16 acc[2][2];
         tile_mainloop<false, false, VEC, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
-        const int c0 = n0 + acc_col<2>(0), c1 = n0 + acc_col<2>(1);
-        const bool ok0 = c0 < N, ok1 = c1 < N;
-        const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
+        // logits (+bias; columns past N masked) -> LDS image [128][132]
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n0 + acc_col<2>(nt);
+            const bool ok = c < N;
+            const float bv = (bias && ok) ? bias[c] : 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float x0 = ok0 ? acc[mt][0][r] + b0 : NEG_BIG;
-                const float x1 = ok1 ? acc[mt][1][r] + b1 : NEG_BIG;
-                if (STORE) { acc[mt][0][r] = x0; acc[mt][1][r] = x1; }
-                const float mo = rm[mt][r];
-                const float mn = fmaxf(mo, fmaxf(x0, x1));
-                rs[mt][r] = rs[mt][r] * __expf(mo - mn) + __expf(x0 - mn) + __expf(x1 - mn);
-                if (ARG) {
-                    if (x0 > mo && x0 >= x1) ra[mt][r] = c0;
-                    else if (x1 > mo) ra[mt][r] = c1;
-                }
-                rm[mt][r] = mn;
-            }
-        // side output: the logits of this row chunk into the cache-resident slab
-        if (STORE) tile_to_global<2, 2>(acc, lds, logits, ldl, m0, n0, M, N, 0.f, lvec != 0);
-    }
-    // reduce over the 32 lanes that hold different columns of the same rows
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float m = rm[mt][r], s = rs[mt][r];
-            int ai = ra[mt][r];
-#pragma unroll
-            for (int o = 16; o > 0; o >>= 1) {
-                const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
-                const int a2 = __shfl_xor(ai, o, 64);
-                const float mn = fmaxf(m, m2);
-                s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
-                if (ARG) { if (m2 > m || (m2 == m && a2 < ai)) ai = a2; }
-                m = mn;
-            }
-            rm[mt][r] = m; rs[mt][r] = s; ra[mt][r] = ai;
+                for (int r = 0; r < 16; ++r)
+                    lds[acc_row<2>(mt, r) * LDT + acc_col<2>(nt)] = ok ? acc[mt][nt][r] + bv : NEG_BIG;
         }
-    // combine the two waves that share rows (wc = 0/1) through LDS, then write the split partials
-    float* red = lds;  // [2][BM][3]
-    const int lane = threadIdx.x & 63, wc = (threadIdx.x >> 6) & 1;
-    if ((lane & 31) == 0) {
+        __syncthreads();
+        const int n = n0 + col;
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float* d = red + (wc * BM + acc_row<2>(mt, r)) * 3;
-                d[0] = rm[mt][r]; d[1] = rs[mt][r]; d[2] = __int_as_float(ra[mt][r]);
-            }
-    }
-    __syncthreads();
-    if (threadIdx.x < BM) {
-        const int m = m0 + threadIdx.x;
-        if (m < M) {
-            const float* x0 = red + threadIdx.x * 3;
-            const float* x1 = red + (BM + threadIdx.x) * 3;
-            const float mn = fmaxf(x0[0], x1[0]);
-            const float s = x0[1] * __expf(x0[0] - mn) + x1[1] * __expf(x1[0] - mn);
-            part_max[(int64_t)m * n_split + split] = mn;
-            part_sum[(int64_t)m * n_split + split] = s;
+        for (int i = 0; i < NR; ++i) {
+            const int row = rbase + RPP * i;
+            const float4 v = *reinterpret_cast<const float4*>(lds + row * LDT + col);
+            const float mo = rm[i];
+            const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+            const float mn = fmaxf(mo, m4);
+            rs[i] = rs[i] * __expf(mo - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
             if (ARG) {
-                const int a0 = __float_as_int(x0[2]), a1 = __float_as_int(x1[2]);
-                part_arg[(int64_t)m * n_split + split] = (x1[0] > x0[0] || (x1[0] == x0[0] && a1 < a0)) ? a1 : a0;
+                if (m4 > mo) ra[i] = n + (v.x == m4 ? 0 : (v.y == m4 ? 1 : (v.z == m4 ? 2 : 3)));
             }
+            rm[i] = mn;
+            if (STORE) {
+                // side output: the logits of this row chunk into the cache-resident slab
+                const int m = m0 + row;
+                if (m < M && n < N) {
+                    float* c = logits + (int64_t)m * ldl + n;
+                    if (lvec) {
+                        *reinterpret_cast<float4*>(c) = v;
+                    } else {
+                        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (n + j < N) c[j] = e[j];
+                    }
+                }
+            }
+        }
+        __syncthreads();  // the image aliases the operand buffers of the next tile
+    }
+    // reduce over the 32 lanes that hold the other columns of the same rows, then write the split partials
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+        float m = rm[i], s = rs[i];
+        int ai = ARG ? ra[i] : 0;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
+            const float mn = fmaxf(m, m2);
+            s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
+            if (ARG) {
+                const int a2 = __shfl_xor(ai, o, 64);
+                if (m2 > m || (m2 == m && a2 < ai)) ai = a2;
+            }
+            m = mn;
+        }
+        const int gm = m0 + rbase + RPP * i;
+        if ((threadIdx.x % TPR) == 0 && gm < M) {
+            part_max[(int64_t)gm * n_split + split] = m;
+            part_sum[(int64_t)gm * n_split + split] = s;
+            if (ARG) part_arg[(int64_t)gm * n_split + split] = ai;
         }
     }
 }
