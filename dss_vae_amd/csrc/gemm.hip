@@ -76,70 +76,92 @@ struct Stager {
         }
     }
 
-    __device__ __forceinline__ void load(int k0) {
+    // The tile's loads and LDS stores are cut into 4 parts so that the mainloop can spread them between
+    // the MFMAs of a k-group (one part per MFMA sub-step): item i belongs to part i*4/N.
+    static constexpr int NITEM = VEC ? NV : NS;
+    static constexpr __host__ __device__ bool in_part(int i, int part) { return (i * 4) / NITEM == part; }
+    const float* lbase;   // !TRANS scalar / TRANS: unused
+    int loff;             // !TRANS: column offset inside the chosen panel
+    bool lfirst;
+
+    // per-tile scalars of the load (k range check, panel choice); resets okmask
+    __device__ __forceinline__ void begin_load(int k0) {
+        if (!TRANS) {
+            const int k = k0 + (VEC ? 4 * (int)(threadIdx.x % TPR) : (int)(threadIdx.x % BK));
+            const bool ok = k < K;
+            const int kc = ok ? k : 0;
+            lfirst = kc < K1;
+            loff = lfirst ? kc : kc - K1;
+            okmask = ok ? ~0u : 0u;
+        } else {
+            okmask = 0u;
+        }
+        lk0 = k0;
+    }
+    int lk0;
+
+    __device__ __forceinline__ void load_part(int part) {
         if (!TRANS) {
             if (VEC) {
-                const int k = k0 + 4 * (threadIdx.x % TPR);
-                const bool ok = k < K;
-                const int kc = ok ? k : 0;
-                const bool first = kc < K1;
-                const int off = first ? kc : kc - K1;
-                okmask = ok ? ~0u : 0u;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>((first ? b1[i] : b2[i]) + off);
+                for (int i = 0; i < NV; ++i)
+                    if (in_part(i, part)) v[i] = *reinterpret_cast<const float4*>((lfirst ? b1[i] : b2[i]) + loff);
             } else {
-                const int k = k0 + (threadIdx.x % BK);
-                const bool ok = k < K;
-                const int kc = ok ? k : 0;
-                const bool first = kc < K1;
-                const int off = first ? kc : kc - K1;
-                okmask = ok ? ~0u : 0u;
 #pragma unroll
-                for (int e = 0; e < NS; ++e) {
-                    const int r = min(r0 + (int)(threadIdx.x / BK) + RPS * e, Rtot - 1);
-                    const int64_t ri = rows ? rows[r] : (int64_t)r;
-                    s[e] = first ? p1[ri * ld1 + off] : p2[ri * ld2 + off];
-                }
+                for (int e = 0; e < NS; ++e)
+                    if (in_part(e, part)) {
+                        const int r = min(r0 + (int)(threadIdx.x / BK) + RPS * e, Rtot - 1);
+                        const int64_t ri = rows ? rows[r] : (int64_t)r;
+                        s[e] = lfirst ? p1[ri * ld1 + loff] : p2[ri * ld2 + loff];
+                    }
             }
         } else {
             if (VEC) {
                 constexpr int TPK = R / 4;          // threads per k row
                 constexpr int KSTEP = NTHREADS / TPK;
                 const int r4 = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
-                okmask = 0u;
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int k = k0 + (int)(threadIdx.x / TPK) + KSTEP * i;
-                    const bool ok = k < K;
-                    okmask |= ok ? (1u << i) : 0u;
-                    v[i] = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
-                }
+                for (int i = 0; i < NV; ++i)
+                    if (in_part(i, part)) {
+                        const int k = lk0 + (int)(threadIdx.x / TPK) + KSTEP * i;
+                        const bool ok = k < K;
+                        okmask |= ok ? (1u << i) : 0u;
+                        v[i] = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
+                    }
             } else {
                 constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
                 const int r = min(r0 + (int)(threadIdx.x % R), Rtot - 1);
-                okmask = 0u;
 #pragma unroll
-                for (int e = 0; e < NS; ++e) {
-                    const int k = k0 + (int)(threadIdx.x / R) + KSTEP * e;
-                    const bool ok = k < K;
-                    okmask |= ok ? (1u << e) : 0u;
-                    s[e] = p1[(int64_t)(ok ? k : 0) * ld1 + r];
-                }
+                for (int e = 0; e < NS; ++e)
+                    if (in_part(e, part)) {
+                        const int k = lk0 + (int)(threadIdx.x / R) + KSTEP * e;
+                        const bool ok = k < K;
+                        okmask |= ok ? (1u << e) : 0u;
+                        s[e] = p1[(int64_t)(ok ? k : 0) * ld1 + r];
+                    }
             }
         }
     }
 
-    __device__ __forceinline__ void store(float* img) const {
+    __device__ __forceinline__ void load(int k0) {
+        begin_load(k0);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) load_part(part);
+    }
+
+    __device__ __forceinline__ void store_part(float* img, int part) const {
         if (!TRANS) {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + 4 * (threadIdx.x % TPR)) =
-                        okmask ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (in_part(i, part))
+                        *reinterpret_cast<float4*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + 4 * (threadIdx.x % TPR)) =
+                            okmask ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
-                    img[((threadIdx.x / BK) + RPS * e) * LDK + (threadIdx.x % BK)] = okmask ? s[e] : 0.f;
+                    if (in_part(e, part))
+                        img[((threadIdx.x / BK) + RPS * e) * LDK + (threadIdx.x % BK)] = okmask ? s[e] : 0.f;
             }
         } else {
             if (VEC) {
@@ -147,15 +169,22 @@ struct Stager {
                 constexpr int KSTEP = NTHREADS / TPK;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) =
-                        ((okmask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (in_part(i, part))
+                        *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) =
+                            ((okmask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
             } else {
                 constexpr int KSTEP = NTHREADS / R;
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
-                    img[((threadIdx.x / R) + KSTEP * e) * (R + 4) + (threadIdx.x % R)] = ((okmask >> e) & 1u) ? s[e] : 0.f;
+                    if (in_part(e, part))
+                        img[((threadIdx.x / R) + KSTEP * e) * (R + 4) + (threadIdx.x % R)] = ((okmask >> e) & 1u) ? s[e] : 0.f;
             }
         }
+    }
+
+    __device__ __forceinline__ void store(float* img) const {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) store_part(img, part);
     }
 };
 
@@ -196,19 +225,25 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
     // Rotated software pipeline.  Per k-tile: NG groups of 8 k (4 MFMAs per 32x32 tile each); the
-    // fragments of group g+1 are read from LDS while group g multiplies.  The staged registers of tile
-    // kt+1 are written to the other LDS buffer and the barrier is passed BEFORE the last group of tile kt
-    // multiplies, and the first fragments of tile kt+1 are fetched right behind the barrier: the barrier
-    // skew and the LDS latency at the tile boundary hide behind that last group's MFMAs instead of
-    // draining the matrix pipe.  Global loads run a whole k-tile ahead of their LDS stores.
+    // fragments of group g+1 are read from LDS while group g multiplies.  The staging of the following
+    // tiles rides BETWEEN the MFMAs (the matrix pipe is busy 64 cycles per MFMA, the wave issues the
+    // staging instructions meanwhile): group 0 writes the staged registers of tile kt+1 to the other LDS
+    // buffer, one quarter per MFMA sub-step, group 1 issues the global loads of tile kt+2 the same way
+    // (global loads run ~a k-tile ahead of their LDS stores).  No branches: the last iterations re-read
+    // the last k-tile (cache hits) and write it to a buffer nobody reads.  The barrier is passed BEFORE
+    // the last group of tile kt multiplies, and the first fragments of tile kt+1 are fetched right behind
+    // it: the barrier skew and the LDS latency at the tile boundary hide behind that group's MFMAs.
     constexpr int NG = BK / 8;
+    static_assert(NG >= 4 && (NG % 2) == 0, "the rotation needs an even number (>= 4) of k-groups per tile");
+    constexpr int G_STORE = 0, G_LOAD = 1;  // the loads overwrite the registers (and okmask) the stores read
     sa.load(kt0 * BK);
     sb.load(kt0 * BK);
     sa.store(As);
     sb.store(Bs);
-    if (kt0 + 1 < kt1) {
-        sa.load((kt0 + 1) * BK);
-        sb.load((kt0 + 1) * BK);
+    {
+        const int k1 = min(kt0 + 1, kt1 - 1) * BK;
+        sa.load(k1);
+        sb.load(k1);
     }
     __syncthreads();
     float fa[2][WM][4], fb[2][WN][4];
@@ -221,6 +256,9 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
         const bool more = kt + 1 < kt1;
         const float* Ab = As + cur * AF;
         const float* Bb = Bs + cur * BF;
+        float* An = As + (cur ^ 1) * AF;
+        float* Bn = Bs + (cur ^ 1) * BF;
+        const int k2 = min(kt + 2, kt1 - 1) * BK;
 #pragma unroll
         for (int g = 0; g < NG - 1; ++g) {
             const int c = g & 1, n = c ^ 1;
@@ -228,29 +266,30 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
             for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
 #pragma unroll
             for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int jj = 0; jj < 4; ++jj)
+            for (int jj = 0; jj < 4; ++jj) {
 #pragma unroll
                 for (int i = 0; i < WM; ++i)
 #pragma unroll
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);  // keep the groups apart: reads of g+1, then MFMAs of g
-        }
-        if (more) {
-            sa.store(As + (cur ^ 1) * AF);
-            sb.store(Bs + (cur ^ 1) * BF);
-            if (kt + 2 < kt1) {
-                sa.load((kt + 2) * BK);
-                sb.load((kt + 2) * BK);
+                if (g == G_STORE) {
+                    sa.store_part(An, jj);
+                    sb.store_part(Bn, jj);
+                }
+                if (g == G_LOAD) {
+                    if (jj == 0) { sa.begin_load(k2); sb.begin_load(k2); }
+                    sa.load_part(jj);
+                    sb.load_part(jj);
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the sub-steps apart: MFMAs, then their share of staging
             }
         }
         __syncthreads();
         constexpr int cl = (NG - 1) & 1, nl = cl ^ 1;  // NG is even: the next tile's group 0 lands in slot 0
         static_assert(nl == 0, "fragment slot rotation assumes an even number of groups per k-tile");
         if (more) {
-            const float* An = As + (cur ^ 1) * AF;
-            const float* Bn = Bs + (cur ^ 1) * BF;
 #pragma unroll
             for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[nl][i], An, arow + 32 * i, 0, h);
 #pragma unroll
