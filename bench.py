@@ -72,6 +72,7 @@ def parse():
                     help="nccl = RCCL over xGMI (the product); gloo only to rehearse the N>1 code path on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--shapes", action="store_true", help="development aid: per-shape kernel table on stderr")
     ap.add_argument("--cpu-batch", type=int, default=32)
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
@@ -248,6 +249,10 @@ def main():
         }
         if timer is not None:
             summ = timer.summary()
+            if a.shapes:
+                for name, detail, n, ms, tf in timer.by_shape():
+                    sys.stderr.write("%-22s %-44s x%5.1f/step %8.3f ms/step %7.1f TFLOP/s\n"
+                                     % (name, detail, n / a.steps, ms / a.steps, tf))
             default_cfg = (a.model, a.batch, a.vocab, a.tree_vocab, a.src_len, a.tree_len, a.variable_lengths,
                            a.stress) == ("SyntaxVAE2", 256, 30000, 300, 30, 90, False, False)
             traffic, traffic_src = pmc_traffic() if default_cfg else ({}, None)

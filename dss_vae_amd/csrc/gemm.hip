@@ -21,6 +21,7 @@
 // dimensions / K are not multiples of 4 floats take the scalar-load instantiation (same math).
 #include "common.h"
 #include <hip/amd_detail/amd_hip_unsafe_atomics.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -691,6 +692,12 @@ int n_cus_cached() {
     return cus;
 }
 
+// development knobs read from the environment at every call (cheap next to a launch)
+int tune_env(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 template <bool TA, bool TB, bool VEC, int WM, int WN>
 int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                  float alpha, float beta, int ksplit_req, hipStream_t s) {
@@ -699,7 +706,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     const int nk = (K + BK - 1) / BK;
     int ksplit = ksplit_req;
     if (ksplit <= 0) {  // auto: fill ~2 workgroups per CU, keep >= 8 k-tiles per split
-        const int slots = 2 * n_cus_cached();
+        const int slots = tune_env("DSSVAE_GEMM_SLOTS", 2) * n_cus_cached();
         ksplit = 1;
         if (ntiles * 2 <= slots) ksplit = min(slots / ntiles, max(1, nk / 8));
     }
@@ -724,9 +731,15 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
 template <bool TA, bool TB, bool VEC>
 int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                       float alpha, float beta, int ksplit, hipStream_t s) {
-    // 128x64 tiles when they waste fewer columns than 128x128 or when 128x128 would under-fill the chip
+    // 128x64 tiles when they waste fewer columns than 128x128, or when 128x128 would under-fill the chip
+    // and K is too short for split-K to make up for it (the wider tile does twice the MFMAs per staged byte)
     const int t128 = (N + 127) / 128, t64 = (N + 63) / 64;
-    const bool narrow = (t64 * 64 < t128 * 128) || ((int64_t)((M + 127) / 128) * t128 < n_cus_cached());
+    const int64_t n128 = (int64_t)((M + 127) / 128) * t128;
+    const int nk8 = max(1, ((K + BK - 1) / BK) / 8);  // splits that still leave >= 8 k-tiles each
+    bool narrow = (t64 * 64 < t128 * 128) || (n128 < n_cus_cached() && n128 * min(nk8, ksplit > 0 ? ksplit : nk8) < n_cus_cached());
+    const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width
+    if (force == 64) narrow = true;
+    if (force == 128) narrow = false;
     if (narrow) return launch_store<TA, TB, VEC, 2, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
     return launch_store<TA, TB, VEC, 2, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
 }

@@ -21,7 +21,7 @@ class KernelTimer(object):
     def summary(self):
         """-> {kernel: dict(launches, total_ms, avg_ms, flops, bytes)}; call after a device sync."""
         out = {}
-        for name, e0, e1, fl, by, st in self.spans:
+        for name, e0, e1, fl, by, st, _detail in self.spans:
             d = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, timesteps=0))
             d["launches"] += 1
             d["total_ms"] += e0.elapsed_time(e1)
@@ -32,15 +32,26 @@ class KernelTimer(object):
             d["avg_ms"] = d["total_ms"] / d["launches"]
         return out
 
+    def by_shape(self):
+        """-> [(kernel, shape string, launches, total_ms, TFLOP/s)] sorted by time (development aid)."""
+        out = {}
+        for name, e0, e1, fl, by, st, detail in self.spans:
+            d = out.setdefault((name, detail), [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += fl
+        rows = [(k[0], k[1], v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12 if v[1] > 0 else 0.0) for k, v in out.items()]
+        return sorted(rows, key=lambda r: -r[3])
+
 
 PROFILE = None
 
 
 class _Span(object):
-    __slots__ = ("name", "flops", "bytes", "e0", "steps")
+    __slots__ = ("name", "flops", "bytes", "e0", "steps", "detail")
 
-    def __init__(self, name, flops, nbytes, steps=0):
-        self.name, self.flops, self.bytes, self.steps = name, flops, nbytes, steps
+    def __init__(self, name, flops, nbytes, steps=0, detail=None):
+        self.name, self.flops, self.bytes, self.steps, self.detail = name, flops, nbytes, steps, detail
 
     def __enter__(self):
         if PROFILE is not None:
@@ -52,7 +63,8 @@ class _Span(object):
         if PROFILE is not None:
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
-            PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes), int(self.steps)))
+            PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes), int(self.steps),
+                                  self.detail))
         return False
 
 
@@ -82,7 +94,8 @@ def _rows(t):
 # ----------------------------------------------------------------------------------------------
 def _gemm(A, lda, ta, B, ldb, tb, Cm, ldc, bias, M, N, K, alpha=1.0, beta=0.0, a_rows=None):
     L.require_cuda(A, B, Cm)
-    with _Span("gemm_store_kernel", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N)):
+    with _Span("gemm_store_kernel", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
+               detail="%s%s M=%d N=%d K=%d%s" % ("t" if ta else "n", "n" if tb else "t", M, N, K, " +=" if beta else "")):
         L.check(L.load().dssvae_gemm_f32(L.ptr(A), lda, int(ta), L.ptr(a_rows), L.ptr(B), ldb, int(tb), L.ptr(Cm),
                                          ldc, L.ptr(bias), M, N, K, alpha, beta, L.stream()), "dssvae_gemm_f32")
 
@@ -270,11 +283,12 @@ def reparam_kl(mean, logv, eps):
 # Fused vocabulary projection + cross-entropy
 # ----------------------------------------------------------------------------------------------
 def _pick_split(M, N):
+    """column splits of the LSE kernel: about two workgroups per CU (its occupancy), every split the same
+    number of 128-column tiles (the kernel lasts as long as its longest split)"""
     tiles_m, tiles_n = (M + 127) // 128, (N + 127) // 128
-    s = 1
-    while tiles_m * s < 2 * n_cus() and s * 2 <= tiles_n and s < 64:
-        s *= 2
-    return s
+    s = max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
+    per = (tiles_n + s - 1) // s
+    return (tiles_n + per - 1) // per
 
 
 def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None):
@@ -284,7 +298,8 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None,
     ps = torch.empty(M, S, device=dev, dtype=torch.float32)
     pa = torch.empty(M, S, device=dev, dtype=torch.int64) if want_arg else None
     lib = L.load()
-    with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S)):
+    with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S),
+               detail="M=%d N=%d K=%d+%d S=%d%s" % (M, N, Kh, Ke, S, " store" if logits is not None else "")):
         L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
                                           L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
                                           0 if logits is None else logits.stride(0), L.stream()),
@@ -699,7 +714,8 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save[i] else 4) for i in launch)
-            with _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch)):
+            with _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch),
+                       detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
                 L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
             _note_persistent_error(wsb)
             if meta.get("check"):
@@ -752,7 +768,8 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
-            with _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch)):
+            with _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch),
+                       detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
                 L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
             _note_persistent_error(wsb)
             if meta.get("check"):
