@@ -698,6 +698,33 @@ int tune_env(const char* name, int dflt) {
     return v ? atoi(v) : dflt;
 }
 
+// Launch plan of a STORE GEMM: tile width and split-K factor from a small cost model, in units of one
+// 128x128 k-tile (64 MFMAs per wave).  The grid runs in rounds of `slots` co-resident workgroups
+// (2 per CU); a workgroup costs a prologue + its k-tiles + an epilogue (dearer when it leaves through
+// atomics).  A 128x64 k-tile takes 0.535 of a 128x128 one (measured: tools/gemm_sweep.py).
+struct StorePlan { int ksplit; float cost; };
+StorePlan plan_store(int M, int N, int K, int bn, bool may_split) {
+    const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
+    const int nk = (K + BK - 1) / BK;
+    const int slots = tune_env("DSSVAE_GEMM_SLOTS", 2) * n_cus_cached();
+    const float c_tile = bn == 128 ? 1.f : 0.535f, c_pro = 1.f, c_epi = bn == 128 ? 2.f : 1.2f;
+    StorePlan best = {1, 3.0e38f};
+    const int ks_max = may_split ? max(1, min(nk / 4, 64)) : 1;
+    for (int ks = 1; ks <= ks_max; ++ks) {
+        const int ktps = (nk + ks - 1) / ks;
+        if ((nk + ktps - 1) / ktps != ks) continue;  // same launch as a smaller ks
+        const int64_t wgs = (int64_t)tiles * ks;
+        const float rounds = (float)((wgs + slots - 1) / slots);
+        // a partly filled last round runs faster per workgroup (the CU's matrix pipe is shared by fewer)
+        const float frac_last = (float)(wgs - (int64_t)(rounds - 1.f) * slots) / (float)slots;
+        const float eff_rounds = (rounds - 1.f) + (frac_last > 0.5f ? 1.f : 0.6f);
+        const float epi = ks > 1 ? 1.5f * c_epi : c_epi;
+        const float cost = eff_rounds * (c_pro + ktps * c_tile + epi) + (ks > 1 ? 1.f : 0.f);
+        if (cost < best.cost) { best.ksplit = ks; best.cost = cost; }
+    }
+    return best;
+}
+
 template <bool TA, bool TB, bool VEC, int WM, int WN>
 int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                  float alpha, float beta, int ksplit_req, hipStream_t s) {
@@ -705,11 +732,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN, ntiles = tiles_m * tiles_n;
     const int nk = (K + BK - 1) / BK;
     int ksplit = ksplit_req;
-    if (ksplit <= 0) {  // auto: fill ~2 workgroups per CU, keep >= 8 k-tiles per split
-        const int slots = tune_env("DSSVAE_GEMM_SLOTS", 2) * n_cus_cached();
-        ksplit = 1;
-        if (ntiles * 2 <= slots) ksplit = min(slots / ntiles, max(1, nk / 8));
-    }
+    if (ksplit <= 0) ksplit = plan_store(M, N, K, BN, beta == 0.f || beta == 1.f).ksplit;
     if (beta != 0.f && beta != 1.f) ksplit = 1;
     ksplit = max(1, min(ksplit, nk));
     int ktps = (nk + ksplit - 1) / ksplit;
@@ -731,12 +754,9 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
 template <bool TA, bool TB, bool VEC>
 int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                       float alpha, float beta, int ksplit, hipStream_t s) {
-    // 128x64 tiles when they waste fewer columns than 128x128, or when 128x128 would under-fill the chip
-    // and K is too short for split-K to make up for it (the wider tile does twice the MFMAs per staged byte)
-    const int t128 = (N + 127) / 128, t64 = (N + 63) / 64;
-    const int64_t n128 = (int64_t)((M + 127) / 128) * t128;
-    const int nk8 = max(1, ((K + BK - 1) / BK) / 8);  // splits that still leave >= 8 k-tiles each
-    bool narrow = (t64 * 64 < t128 * 128) || (n128 < n_cus_cached() && n128 * min(nk8, ksplit > 0 ? ksplit : nk8) < n_cus_cached());
+    // tile width (128x128 or 128x64) by the cost model above
+    const bool may_split = (beta == 0.f || beta == 1.f) && ksplit <= 0;
+    bool narrow = plan_store(M, N, K, 64, may_split).cost < plan_store(M, N, K, 128, may_split).cost;
     const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width
     if (force == 64) narrow = true;
     if (force == 128) narrow = false;

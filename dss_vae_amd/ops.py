@@ -312,7 +312,11 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None,
 
 
 import os as _os
-SLAB_BYTES = int(_os.environ.get("DSSVAE_SLAB_MB", "128")) << 20  # dlogits slab: sized to stay inside the 256 MiB Infinity Cache
+# dlogits slab of one row chunk.  Measured on the headline workload (bench.py --shapes, DSSVAE_SLAB_MB sweep):
+# 128 MiB (inside the 256 MiB Infinity Cache) 5.88k sentences/s, 256 MiB 6.02k, 512 MiB 6.09k -- the consumers
+# of the slab are MFMA-bound GEMMs that take it from HBM just as well, while longer chunks quantise better
+# over the chip (LSE: 3.67 -> 14.2 rounds of workgroups) and pass over dW fewer times.
+SLAB_BYTES = int(_os.environ.get("DSSVAE_SLAB_MB", "512")) << 20
 
 
 def _col_chunks(M, N):
