@@ -402,7 +402,10 @@ class _LinearCEFn(Function):
             slabs = [torch.empty(min(mc, M), ldd, device=dev, dtype=torch.float32) for _ in range(n_str)]
             lse = torch.empty(M, device=dev, dtype=torch.float32)
             need_x = need_xh or need_xe
-            dx = torch.empty(M, K, device=dev, dtype=torch.float32) if need_x else None
+            # only the panels whose input wants a gradient (a frozen adversary's embedding panel does not:
+            # half of its dgrad GEMM)
+            kx0, kx1 = (0 if need_xh else Kh), (K if need_xe else Kh)
+            dx = torch.empty(M, kx1 - kx0, device=dev, dtype=torch.float32) if need_x else None
             dW = torch.empty(N, K, device=dev, dtype=torch.float32) if need_w else None
             db = torch.zeros(N, device=dev, dtype=torch.float32) if need_b else None
             ones = torch.ones(M, T, device=dev, dtype=torch.float32)
@@ -428,7 +431,7 @@ class _LinearCEFn(Function):
                                                   rows, 0, N, L.ptr(db), L.stream()), "dssvae_onehot_sub")
                     dlv = dl[:, :N]
                     if need_x:
-                        mm_nn(dlv, W, out=dx[m0:m0 + rows])
+                        mm_nn(dlv, W[:, kx0:kx1], out=dx[m0:m0 + rows])
                     if need_w:
                         if wg_done is not None and n_str > 1:
                             st.wait_event(wg_done)
@@ -439,7 +442,7 @@ class _LinearCEFn(Function):
             for st in streams[1:]:
                 main.wait_stream(st)
             ctx.unit_grads = (dx, dW, db)
-            ctx.Kh = Kh
+            ctx.Kh, ctx.kx0 = Kh, kx0
         picked = torch.empty(M, T, device=dev, dtype=torch.float32)
         L.check(lib.dssvae_picked_logit(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b),
                                         L.ptr(target), T, ctx.ignore, M, L.ptr(picked), L.stream()),
@@ -462,8 +465,8 @@ class _LinearCEFn(Function):
             dxh = dxe = None
             if dx is not None:
                 dx.mul_(g.unsqueeze(1))
-                dxh = dx[:, :ctx.Kh] if need_xh else None
-                dxe = dx[:, ctx.Kh:] if (need_xe and dx.size(1) > ctx.Kh) else None
+                dxh = dx[:, :ctx.Kh] if need_xh else None  # kx0 == 0 whenever the h panel is wanted
+                dxe = dx[:, ctx.Kh - ctx.kx0:] if need_xe else None
             if dW is not None:
                 dW.mul_(c)
             if db is not None:

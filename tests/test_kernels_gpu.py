@@ -84,7 +84,8 @@ def test_linear_ce_forward_backward(M, Kh, Ke, N, T):
 
 @pytest.mark.parametrize("M,Kh,Ke,N,T,frozen", [(7, 8, 4, 11, 1, False), (300, 120, 20, 2000, 1, False),
                                                 (37, 16, 0, 515, 9, False), (256, 600, 0, 3001, 32, True),
-                                                (130, 30, 18, 777, 1, False), (520, 64, 32, 1300, 1, True)])
+                                                (130, 30, 18, 777, 1, False), (520, 64, 32, 1300, 1, True),
+                                                (520, 64, 32, 1300, 1, "xe_only")])
 def test_linear_ce_uniform_upstream_schedule(M, Kh, Ke, N, T, frozen, monkeypatch):
     """uniform_upstream=True: logits of a row chunk go to a slab in the forward pass, gradients for
     upstream 1 are produced there and scaled in backward; same numbers as the reference when every
@@ -104,8 +105,12 @@ def test_linear_ce_uniform_upstream_schedule(M, Kh, Ke, N, T, frozen, monkeypatc
     ref = ce_reference(*leaves, tgt, 0)
     (ref.sum() * scale).backward()
     dl = [t.clone().to(DEV).requires_grad_(True) if t is not None else None for t in (xh, xe, W, b)]
-    if frozen:
+    if frozen == "xe_only":  # only the embedding panel wants a gradient
+        dl[0].requires_grad_(False)
+    elif frozen:
         dl[2].requires_grad_(False), dl[3].requires_grad_(False)
+        if dl[1] is not None:  # a frozen adversary's embedding panel: only the h panel of dX is produced
+            dl[1].requires_grad_(False)
     out = ops.linear_ce(dl[0], dl[1], dl[2], dl[3], tgt.to(DEV), 0, uniform_upstream=True)
     close(out, ref, rtol=1e-5, atol=1e-4, what="nll")
     (out.sum() * scale).backward()
