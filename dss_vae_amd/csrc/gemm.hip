@@ -738,8 +738,8 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     int ktps = (nk + ksplit - 1) / ksplit;
     ksplit = (nk + ktps - 1) / ktps;  // no empty splits
     if (ksplit > 1 && beta == 0.f) {
-        hipError_t e = hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, s);
-        if (e != hipSuccess) return (int)e;
+        const int e = dssvae_zero2d(C, ldc, M, N, s);
+        if (e != DSSVAE_OK) return e;
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
     auto kern = gemm_store_kernel<TA, TB, VEC, WM, WN>;
@@ -907,8 +907,8 @@ extern "C" int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* o
     if (!X || !out || M <= 0 || N <= 0) return DSSVAE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) {
-        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), s);
-        if (e != hipSuccess) return (int)e;
+        const int e = dssvae_zero2d(out, N, 1, N, s);
+        if (e != DSSVAE_OK) return e;
     }
     const int col_blocks = (N + 63) / 64;
     int row_blocks = max(1, min((M + 63) / 64, (4 * n_cus_cached() + col_blocks - 1) / col_blocks));

@@ -444,8 +444,9 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
     if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, L.header_bytes, s);
-    if (e != hipSuccess) return (int)e;
+    const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
+                                (int)(L.header_bytes / 4), s);
+    if (e != DSSVAE_OK) return e;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(gru_fwd_kernel, dim3(wg), dim3(NTHR), lds_bytes, s, args);
@@ -483,8 +484,9 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
     if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
     hipStream_t s = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(workspace, 0, L.header_bytes, s);
-    if (e != hipSuccess) return (int)e;
+    const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
+                                (int)(L.header_bytes / 4), s);
+    if (e != DSSVAE_OK) return e;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     hipLaunchKernelGGL(gru_bwd_kernel, dim3(wg), dim3(NTHR), lds_bytes, s, args);
