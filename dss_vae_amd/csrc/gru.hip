@@ -23,16 +23,15 @@
 //
 // Roofline: per step 2*B*H*3H flop on fp32 MFMA; in practice latency-bound by the step hand-off.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BB = 64;   // batch rows per workgroup (4 waves x 16 rows)
+constexpr int BB = 64;   // batch rows per workgroup with 4 waves (16 rows per wave); 128 with 8 waves
 constexpr int UU = 16;   // hidden units per workgroup (M of the 16x16x4 MFMA)
-constexpr int NTHR = 256;
 constexpr int CH = 8;    // exchange slices fetched per register chunk
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 constexpr int CNT_STRIDE = 32;  // one 128-B line per counter
-constexpr int BLK = BB * UU;    // floats in one [64 rows][16 units] exchange block
 
 typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 
@@ -129,7 +128,11 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, in
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
+// WV waves per workgroup: 4 (64 batch rows) or 8 (128 rows: half the workgroups per recurrence, two waves per
+// SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
+template <int WV>
+__global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
+    constexpr int BB = 16 * WV, NTHR = 64 * WV, BLK = BB * UU;
     // Ws[g][slice s][c][kq][j] = whh[(g*H + u0 + j)*H + 16 s + 4 kq + c]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -247,7 +250,11 @@ __global__ __launch_bounds__(NTHR) void gru_fwd_kernel(FwdArgs args) {
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHR) void gru_bwd_kernel(BwdArgs args) {
+// WV waves per workgroup: 4 (64 batch rows) or 8 (128 rows: half the workgroups per recurrence, two waves per
+// SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
+template <int WV>
+__global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
+    constexpr int BB = 16 * WV, NTHR = 64 * WV, BLK = BB * UU;
     // chunk q = 3*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -387,7 +394,7 @@ Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     L.header_bytes = off;
     for (int i = 0; i < n_inst; ++i) {
         L.buf_off[i] = off;
-        off += (size_t)2 * ((B[i] + BB - 1) / BB) * BB * 3 * round16(H[i]) * sizeof(float);
+        off += (size_t)2 * ((B[i] + 127) / 128) * 128 * 3 * round16(H[i]) * sizeof(float);  // either block size
         off = (off + 255) & ~(size_t)255;
     }
     L.total_bytes = off;
@@ -402,6 +409,22 @@ int cu_count() {
         cus = n;
     }
     return cus;
+}
+
+// waves per workgroup of a launch: 4 (one workgroup per 64 rows x 16 units) when every cell gets its own
+// CU, else 8 (128 rows per workgroup); 0 = does not fit either way.  DSSVAE_GRU_WAVES=8 forces 8 (tests).
+int pick_waves(int n_inst, const int32_t* B, const int32_t* H) {
+    int wg4 = 0, wg8 = 0;
+    for (int i = 0; i < n_inst; ++i) {
+        const int ns = round16(H[i]) / UU;
+        wg4 += ((B[i] + 63) / 64) * ns;
+        wg8 += ((B[i] + 127) / 128) * ns;
+    }
+    const char* f = getenv("DSSVAE_GRU_WAVES");
+    if (f && atoi(f) == 8 && wg8 <= cu_count()) return 8;
+    if (wg4 <= cu_count()) return 4;
+    if (wg8 <= cu_count()) return 8;
+    return 0;
 }
 
 }  // namespace
@@ -429,12 +452,15 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     FwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
+    const int wv = pick_waves(n_inst, Bs, Hs);
+    if (wv == 0) return DSSVAE_ETOOBIG;
+    const int bbk = 16 * wv;
     int wg = 0, max_ns = 0;
     for (int i = 0; i < n_inst; ++i) {
         FwdDev& d = args.inst[i];
         d.in = inst[i];
         d.n_slices = round16(inst[i].H) / UU;
-        d.n_bblocks = (inst[i].B + BB - 1) / BB;
+        d.n_bblocks = (inst[i].B + bbk - 1) / bbk;
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
@@ -447,9 +473,10 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_fwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(gru_fwd_kernel, dim3(wg), dim3(NTHR), lds_bytes, s, args);
+    auto kern = wv == 4 ? gru_fwd_kernel<4> : gru_fwd_kernel<8>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wv), lds_bytes, s, args);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -469,12 +496,15 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     BwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
+    const int wv = pick_waves(n_inst, Bs, Hs);
+    if (wv == 0) return DSSVAE_ETOOBIG;
+    const int bbk = 16 * wv;
     int wg = 0, max_ns = 0;
     for (int i = 0; i < n_inst; ++i) {
         BwdDev& d = args.inst[i];
         d.in = inst[i];
         d.n_slices = round16(inst[i].H) / UU;
-        d.n_bblocks = (inst[i].B + BB - 1) / BB;
+        d.n_bblocks = (inst[i].B + bbk - 1) / bbk;
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
@@ -487,9 +517,10 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gru_bwd_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-    hipLaunchKernelGGL(gru_bwd_kernel, dim3(wg), dim3(NTHR), lds_bytes, s, args);
+    auto kern = wv == 4 ? gru_bwd_kernel<4> : gru_bwd_kernel<8>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wv), lds_bytes, s, args);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -554,13 +554,18 @@ GRU_LDS_BUDGET = 150 * 1024
 FORCE_STEPWISE_GRU = False  # tests: send every recurrence down the stepwise path
 
 
+def _cells(B, H):
+    """workgroups a recurrence needs at least in a persistent launch: one per (128 batch rows) x (slice of 16
+    hidden units); the library takes 64-row workgroups when the whole launch fits that way"""
+    return ((B + 127) // 128) * ((H + 15) // 16)
+
+
 def _fits_persistent(B, H):
-    """can one persistent launch hold this recurrence?  (one workgroup per CU for 64 rows x 16 units,
-    its W_hh slice 3 x 16 x H fp32 resident in LDS)"""
-    ns = (H + 15) // 16
+    """can one persistent launch hold this recurrence?  (one workgroup per CU, its W_hh slice
+    3 x 16 x H fp32 resident in LDS)"""
     if FORCE_STEPWISE_GRU:
         return False
-    return ((B + 63) // 64) * ns <= n_cus() and 3 * ns * 1024 <= GRU_LDS_BUDGET
+    return _cells(B, H) <= n_cus() and 3 * ((H + 15) // 16) * 1024 <= GRU_LDS_BUDGET
 
 
 def _gru_steps_fwd(x, whh, bhh, h0, lengths, reverse, o, col, hl, gates):
@@ -618,7 +623,7 @@ def _pack(insts):
     launches = []  # [indices, workgroups]
     for i in sorted(range(len(insts)), key=lambda i: -insts[i][2]):
         B, H, _ = insts[i]
-        need = ((B + 63) // 64) * ((H + 15) // 16)
+        need = _cells(B, H)
         if need > cus:
             raise RuntimeError("GRU instance B=%d H=%d needs %d workgroups > %d CUs: not supported by the "
                                "persistent kernel yet" % (B, H, need, cus))

@@ -184,11 +184,16 @@ def gru_reference(x, h0, wih, whh, bih, bhh, lengths, reverse):
 
 @pytest.mark.parametrize("B,T,H,I,packed", [(3, 4, 8, 5, False), (70, 6, 30, 12, True), (64, 9, 150, 20, True),
                                             (130, 5, 300, 16, False), (256, 4, 600, 8, False)])
-@pytest.mark.parametrize("stepwise", [False, True])
+@pytest.mark.parametrize("stepwise", [False, True, "waves8"])
 def test_persistent_gru_forward_backward(B, T, H, I, packed, stepwise, monkeypatch):
     """two instances (forward + reverse direction) in one persistent launch -- or, stepwise=True, down the
-    per-timestep GEMM + gate-kernel path that oversized recurrences take -- vs explicit equations"""
+    per-timestep GEMM + gate-kernel path that oversized recurrences take; "waves8": the persistent kernel
+    with 128-row workgroups (what a launch that does not fit one 64-row cell per CU uses) -- vs explicit
+    equations"""
     from dss_vae_amd import ops
+    if stepwise == "waves8":
+        monkeypatch.setenv("DSSVAE_GRU_WAVES", "8")
+        stepwise = False
     monkeypatch.setattr(ops, "FORCE_STEPWISE_GRU", stepwise)
     g = torch.Generator().manual_seed(B + H)
     lengths = None
@@ -257,7 +262,7 @@ def test_gru_cell_and_no_h0():
 def test_oversized_gru_takes_the_stepwise_path():
     """H = 1024 does not fit the persistent kernel's LDS budget (3 * 64 slices * 1 KiB > 150 KiB)"""
     from dss_vae_amd import ops
-    assert not ops._fits_persistent(8, 1024) and not ops._fits_persistent(1024, 512) and ops._fits_persistent(256, 600)
+    assert not ops._fits_persistent(8, 1024) and not ops._fits_persistent(2048, 512) and ops._fits_persistent(256, 600)
     B, T, H = 8, 3, 1024
     x, whh, bhh, h0 = rnd(B, T, 3 * H, seed=4), rnd(3 * H, H, seed=5, scale=0.03), rnd(3 * H, seed=6), rnd(B, H, seed=7)
     with torch.no_grad():
