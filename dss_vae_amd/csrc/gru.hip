@@ -9,15 +9,17 @@
 //     registers and stores its 16x16 piece of h_t;
 //   * the state is exchanged through a ping-pong buffer laid out [slice][row][16 units], so a
 //     workgroup publishes ONE contiguous 4 KB block and a reading wave takes 1 KB contiguous per
-//     slice; workgroups of the same (instance, batch block) meet on one monotonic arrival counter
-//     per step -- there is no grid-wide barrier, and independent instances / batch blocks never
+//     slice; the waves that own the same 16 batch rows in the workgroups of one (instance, batch
+//     block) meet on one monotonic arrival counter per step -- there is no grid-wide barrier and no
+//     workgroup barrier in the step loop, and independent instances / batch blocks / row groups never
 //     wait for each other.
 // Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first table row): EVERY byte of
 // the exchange buffer is stored write-through (buffer_store_dwordx4 sc1) and EVERY load of it is a
 // buffer_load_dwordx4 sc1 (bypasses the CU's L1), so no release / acquire cache maintenance is
-// needed: each storing wave drains its stores (s_waitcnt vmcnt(0)), the workgroup barrier joins
-// them, one lane adds to the counter (agent-scope atomic); the consumer's lane 0 polls the counter
-// with sc1 loads, then the workgroup barrier, then the sc1 loads.
+// needed: a storing wave drains its stores (s_waitcnt vmcnt(0)), then its lane 0 adds to the row
+// group's counter (agent-scope atomic); a consuming wave's lane 0 polls that counter with sc1 loads,
+// then the wave issues its sc1 loads (every byte it reads was stored by a wave that signalled after
+// its own drain).
 // All workgroups of a launch must be co-resident: the host caps the grid at the CU count (1
 // workgroup per CU); every spin is bounded and reports through an error word instead of hanging.
 //
@@ -27,7 +29,6 @@
 
 namespace {
 
-constexpr int BB = 64;   // batch rows per workgroup with 4 waves (16 rows per wave); 128 with 8 waves
 constexpr int UU = 16;   // hidden units per workgroup (M of the 16x16x4 MFMA)
 constexpr int CH = 8;    // exchange slices fetched per register chunk
 constexpr unsigned SPIN_LIMIT = 1u << 24;
@@ -68,17 +69,20 @@ __device__ __forceinline__ void st_sc1(f32x4 v, __amdgpu_buffer_rsrc_t r, int vo
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 16);
 }
 
-// every storing wave drains, the barrier joins them, one lane signals (no release fence: the
-// payload stores are write-through)
+// Hand-off at WAVE granularity: wave w of a workgroup owns batch rows 16w..16w+15 of its block and needs,
+// from every peer slice, exactly the rows that the peers' wave w produced.  So each (batch block, wave)
+// row group has its own arrival counter: a wave drains its own write-through stores and signals; a wave
+// polls its own counter and then loads.  No workgroup barrier in the step loop: the waves of a workgroup
+// (and the two waves that share a SIMD in the 8-wave configuration) drift apart, one's MFMAs run under
+// the other's hand-off.
 __device__ __forceinline__ void publish(unsigned* cnt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// one lane polls (sc1 loads), then the barrier; the payload loads that follow are all sc1
+// lane 0 polls (sc1 loads) while the rest of the wave is masked off; the payload loads that follow are all sc1
 __device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* err) {
-    if (threadIdx.x == 0) {
+    if ((threadIdx.x & 63) == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(0);
@@ -92,7 +96,6 @@ __device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* 
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    __syncthreads();
 }
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;                       // first of this lane's 4 units
     const int n_ok = max(0, min(4, H - ub));          // how many of them exist
-    unsigned* cnt = d.counters + (size_t)bblock * CNT_STRIDE;
+    unsigned* cnt = d.counters + ((size_t)bblock * WV + wave) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
     const int gate_stride = NS * 256;
 
@@ -176,6 +179,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;  // same lane offset inside every slice block
     const int own = slice * BLK * 4;
 
+    __syncthreads();  // the slice is in LDS for every wave; from here on the waves run free
     // state 0 into the exchange buffer (pad units and pad rows are zero and stay zero)
     float hcur[4] = {0.f, 0.f, 0.f, 0.f};
     if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;
     const int n_ok = max(0, min(4, H - ub));
-    unsigned* cnt = d.counters + (size_t)bblock * CNT_STRIDE;
+    unsigned* cnt = d.counters + ((size_t)bblock * WV + wave) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
 
     for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
@@ -388,7 +392,7 @@ Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     size_t off = 256;  // error word + padding
     for (int i = 0; i < n_inst; ++i) {
         L.cnt_off[i] = off;
-        off += (size_t)((B[i] + BB - 1) / BB) * CNT_STRIDE * sizeof(unsigned);
+        off += (size_t)((B[i] + 127) / 128) * 8 * CNT_STRIDE * sizeof(unsigned);  // one per 16-row group
     }
     off = (off + 255) & ~(size_t)255;
     L.header_bytes = off;

@@ -554,10 +554,13 @@ GRU_LDS_BUDGET = 150 * 1024
 FORCE_STEPWISE_GRU = False  # tests: send every recurrence down the stepwise path
 
 
+GRU_PACK_ROWS = int(_os.environ.get("DSSVAE_GRU_PACK_ROWS", "128"))  # development knob: 64 = never merge into 8-wave launches
+
+
 def _cells(B, H):
     """workgroups a recurrence needs at least in a persistent launch: one per (128 batch rows) x (slice of 16
     hidden units); the library takes 64-row workgroups when the whole launch fits that way"""
-    return ((B + 127) // 128) * ((H + 15) // 16)
+    return ((B + GRU_PACK_ROWS - 1) // GRU_PACK_ROWS) * ((H + 15) // 16)
 
 
 def _fits_persistent(B, H):
