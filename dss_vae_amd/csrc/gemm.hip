@@ -365,13 +365,11 @@ __device__ __forceinline__ void tile_to_global(const f32x16 (&acc)[WM][WN], floa
 
 // ---- STORE ---------------------------------------------------------------------------------------
 template <bool TA, bool TB, bool VEC, int WM, int WN>
-__global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
-                                                               const float* __restrict__ bias, int M, int N, int K,
-                                                               float alpha, float beta, int tiles_n, int ntiles,
-                                                               int ksplit, int kt_per_split, int cvec) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+__device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
+                                                const float* __restrict__ bias, int M, int N, int K, float alpha,
+                                                float beta, int tiles_n, int ksplit, int kt_per_split, int cvec,
+                                                int wid, float* lds) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
     const int tile = wid / ksplit, ks = wid - tile * ksplit;
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     const int nk = (K + BK - 1) / BK;
@@ -406,6 +404,40 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = alpha * acc[mt][nt][r] + bv;
     }
     tile_to_global<WM, WN>(acc, lds, C, ldc, m0, n0, M, N, beta, cvec != 0);
+}
+
+template <bool TA, bool TB, bool VEC, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
+                                                               const float* __restrict__ bias, int M, int N, int K,
+                                                               float alpha, float beta, int tiles_n, int ntiles,
+                                                               int ksplit, int kt_per_split, int cvec) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
+    store_tile_body<TA, TB, VEC, WM, WN>(a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ksplit, kt_per_split, cvec,
+                                         wid, lds);
+}
+
+// ---- grouped STORE: up to DSSVAE_GEMM_MAX_GROUP independent products of one layout in ONE launch ----
+// (the per-direction / per-head GRU projections and weight gradients are 1-3 GFLOP each: alone they
+// cannot fill the chip and pay a launch + a tail each).  C += A.B^T + bias: the caller zero-fills C.
+struct GroupProblem {
+    OpA a; OpB b;
+    float* C; int64_t ldc; const float* bias;
+    int M, N, K, tiles_n, ksplit, ktps, cvec, wg_begin;
+};
+struct GroupArgs {
+    GroupProblem p[DSSVAE_GEMM_MAX_GROUP];
+    int n;
+};
+
+template <bool TA, bool TB, bool VEC, int WM, int WN>
+__global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    int i = 0;
+    while (i + 1 < g.n && (int)blockIdx.x >= g.p[i + 1].wg_begin) ++i;
+    const GroupProblem& q = g.p[i];
+    store_tile_body<TA, TB, VEC, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 1.f, q.tiles_n, q.ksplit,
+                                         q.ktps, q.cvec, (int)blockIdx.x - q.wg_begin, lds);
 }
 
 // ---- LSE (optionally with argmax) ----------------------------------------------------------------
@@ -793,6 +825,82 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
 #define GO(TA, TB)                                                                                              \
     return vec ? launch_store_tile<TA, TB, true>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)          \
                : launch_store_tile<TA, TB, false>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)
+    if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
+    else { if (trans_b) GO(false, true); else GO(false, false); }
+#undef GO
+}
+
+namespace {
+
+template <bool TA, bool TB, bool VEC, int WM, int WN>
+int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t s) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    // one k-tile count per workgroup for the whole group (they finish together): the smallest that keeps
+    // the launch within one round of 2 workgroups per CU (and >= 4 k-tiles per workgroup)
+    const int slots = 2 * n_cus_cached();
+    int nk_max = 1;
+    for (int i = 0; i < n; ++i) nk_max = max(nk_max, (pr[i].K + BK - 1) / BK);
+    int ktps = min(4, nk_max);
+    for (;; ++ktps) {
+        int64_t wgs = 0;
+        for (int i = 0; i < n; ++i) {
+            const int nk = (pr[i].K + BK - 1) / BK;
+            wgs += (int64_t)((pr[i].M + BM - 1) / BM) * ((pr[i].N + BN - 1) / BN) * ((nk + ktps - 1) / ktps);
+        }
+        if (wgs <= slots || ktps >= nk_max) break;
+    }
+    int wg = 0;
+    for (int i = 0; i < n; ++i) {
+        GroupProblem& q = g.p[i];
+        const int nk = (pr[i].K + BK - 1) / BK;
+        q.tiles_n = (pr[i].N + BN - 1) / BN;
+        q.ktps = min(ktps, nk);
+        q.ksplit = (nk + q.ktps - 1) / q.ktps;
+        q.wg_begin = wg;
+        wg += ((pr[i].M + BM - 1) / BM) * q.tiles_n * q.ksplit;
+    }
+    constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
+    auto kern = gemm_group_kernel<TA, TB, VEC, WM, WN>;
+    allow_lds(kern, lds_bytes);
+    hipLaunchKernelGGL(kern, dim3(wg), dim3(NTHREADS), lds_bytes, s, g);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+}  // namespace
+
+extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int trans_a, int trans_b, void* stream) {
+    if (!pr || n <= 0 || n > DSSVAE_GEMM_MAX_GROUP) return DSSVAE_EINVAL;
+    GroupArgs g;
+    g.n = n;
+    bool vec = true;
+    int64_t padded128 = 0, padded64 = 0;
+    for (int i = 0; i < n; ++i) {
+        const dssvae_gemm_problem& x = pr[i];
+        if (!x.A || !x.B || !x.C || x.M <= 0 || x.N <= 0 || x.K <= 0 || x.ldc < x.N) return DSSVAE_EINVAL;
+        if ((trans_a ? x.lda < x.M : x.lda < x.K) || (trans_b ? x.ldb < x.N : x.ldb < x.K)) return DSSVAE_EINVAL;
+        GroupProblem& q = g.p[i];
+        q.a.p1 = x.A; q.a.ld1 = x.lda; q.a.K1 = x.K; q.a.p2 = nullptr; q.a.ld2 = 0; q.a.rows = nullptr;
+        q.b.p = x.B; q.b.ld = x.ldb;
+        q.C = x.C; q.ldc = x.ldc; q.bias = x.bias;
+        q.M = x.M; q.N = x.N; q.K = x.K;
+        q.cvec = aligned16(x.C) && (x.ldc % 4) == 0 && (x.N % 4) == 0;
+        const bool va = vec_ok(x.A, x.lda) && (trans_a ? (x.M % 4 == 0 && x.M >= 4) : (x.K % 4 == 0));
+        const bool vb = vec_ok(x.B, x.ldb) && (trans_b ? (x.N % 4 == 0 && x.N >= 4) : (x.K % 4 == 0));
+        vec = vec && va && vb;
+        const int64_t tm = (x.M + 127) / 128, nk = (x.K + BK - 1) / BK;
+        padded128 += tm * ((x.N + 127) / 128) * nk * 1000;
+        padded64 += tm * ((x.N + 63) / 64) * nk * 535;
+    }
+    const bool narrow = padded64 < padded128;  // less (efficiency-weighted) padded work in 128x64 tiles
+    hipStream_t s = (hipStream_t)stream;
+#define GO(TA, TB)                                                                                   \
+    do {                                                                                             \
+        if (vec) return narrow ? launch_group<TA, TB, true, 2, 1>(g, pr, n, s)                       \
+                               : launch_group<TA, TB, true, 2, 2>(g, pr, n, s);                      \
+        return narrow ? launch_group<TA, TB, false, 2, 1>(g, pr, n, s)                               \
+                      : launch_group<TA, TB, false, 2, 2>(g, pr, n, s);                              \
+    } while (0)
     if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
     else { if (trans_b) GO(false, true); else GO(false, false); }
 #undef GO

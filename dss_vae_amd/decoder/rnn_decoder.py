@@ -148,19 +148,26 @@ def score_many(jobs):
         embs.append(e)
         xs.append(e)
     for layer in range(n_layers):
-        insts = []
+        insts, proj = [], {True: [], False: []}
         for k, j in enumerate(jobs):
             dec, x = j["dec"], xs[k]
             ng = bool(j.get("no_grad")) or not grad_on
             with torch.set_grad_enabled(not ng):
                 if layer > 0 and dec.training and dec.rnn_droprate > 0.0:
                     x = x * ops.dropout_mask(tuple(x.shape), dec.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
-                wih, whh, bih, bhh = dec.rnn.layer_params(layer)
-                h0 = j["h0"][layer]
-                if ng:
-                    whh, bhh, h0 = whh.detach(), bhh.detach(), h0.detach()
-                insts.append(dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=h0, group=k, col=0,
-                                  save=not ng))
+            wih, whh, bih, bhh = dec.rnn.layer_params(layer)
+            h0 = j["h0"][layer]
+            if ng:
+                whh, bhh, h0 = whh.detach(), bhh.detach(), h0.detach()
+            proj[ng].append((k, (x, wih, bih)))
+            insts.append(dict(whh=whh, bhh=bhh, h0=h0, group=k, col=0, save=not ng))
+        # the input projections of all heads of the layer share grouped MFMA launches (evaluation-only
+        # heads in a group of their own, outside autograd)
+        for ng, items in proj.items():
+            if items:
+                with torch.set_grad_enabled(not ng):
+                    for (k, _), xp in zip(items, ops.linear_many([t for _, t in items])):
+                        insts[k]["xproj"] = xp
         xs, _ = ops.gru_layer(insts)
     res = []
     for k, j in enumerate(jobs):

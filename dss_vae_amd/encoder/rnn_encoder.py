@@ -52,15 +52,18 @@ def encode_many(encoders, input_var, input_lengths=None):
     assert all(e.n_layers == n_layers for e in encoders)
     hns = [[] for _ in encoders]
     for layer in range(n_layers):
-        insts = []
+        insts, proj = [], []
         for ei, e in enumerate(encoders):
             x = xs[ei]
             if layer > 0 and e.training and e.rnn_droprate > 0.0:
                 x = x * ops.dropout_mask(tuple(x.shape), e.rnn_droprate, GLOBAL_SEEDS.next(), dev)
             for di, suffix in enumerate(e.rnn.suffixes()):
                 wih, whh, bih, bhh = e.rnn.layer_params(layer, suffix)
-                insts.append(dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=None, reverse=di == 1,
-                                  group=ei, col=di * e.hidden_size))
+                proj.append((x, wih, bih))
+                insts.append(dict(whh=whh, bhh=bhh, h0=None, reverse=di == 1, group=ei, col=di * e.hidden_size))
+        # the input projections of every direction / encoder of the layer share grouped MFMA launches
+        for inst, xp in zip(insts, ops.linear_many(proj)):
+            inst["xproj"] = xp
         outs, hl = ops.gru_layer(insts, lengths=lens)
         k = 0
         for ei, e in enumerate(encoders):

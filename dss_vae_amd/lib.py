@@ -33,6 +33,14 @@ class GruBwdInst(C.Structure):
                 ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32)]
 
 
+GEMM_MAX_GROUP = 8
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("lda", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("C", C.c_void_p),
+                ("ldc", C.c_int64), ("bias", C.c_void_p), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32)]
+
+
 DECODE_MAX_LAYERS = 4
 
 
@@ -50,6 +58,7 @@ _SIGNATURES = {
     "dssvae_device_cus": ([C.POINTER(C.c_int)], _I),
     "dssvae_gemm_f32": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _P], _I),
     "dssvae_gemm_f32_splitk": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _I, _P], _I),
+    "dssvae_gemm_f32_grouped": ([C.POINTER(GemmProblem), _I, _I, _I, _P], _I),
     "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_softmax_grad_inplace": ([_P, _L, _P, _P, _I, _I, _P, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),

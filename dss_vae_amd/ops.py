@@ -145,6 +145,51 @@ def mm_tn(dy, x, out=None, beta=0.0):
     return out
 
 
+def _gemm_grouped(kind, pairs, biases=None):
+    """kind 'nt': x[M,K] @ w[N,K]^T (+bias) | 'nn': dy[M,N] @ w[N,K] | 'tn': dy[M,N]^T @ x[M,K], for a list
+    of (left, right) operand pairs, in as few launches as the group limit allows; -> list of outputs
+    (views of ONE zero-filled buffer: the grouped kernel accumulates)."""
+    ta, tb = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[kind]
+    probs = []
+    for i, (l, r) in enumerate(pairs):
+        l, ldl = _rows(_f32(l))
+        r, ldr = _rows(_f32(r))
+        if kind == "nt":
+            M, K, N = l.size(0), l.size(1), r.size(0)
+            assert r.size(1) == K
+        elif kind == "nn":
+            M, K, N = l.size(0), l.size(1), r.size(1)
+            assert r.size(0) == K
+        else:
+            M, K, N = l.size(1), l.size(0), r.size(1)
+            assert r.size(0) == K
+        probs.append((l, ldl, r, ldr, M, N, K, None if biases is None else biases[i]))
+    L.require_cuda(*[p[0] for p in probs])
+    dev = probs[0][0].device
+    sizes = [(p[4] * p[5] + 3) // 4 * 4 for p in probs]
+    buf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    outs, off = [], 0
+    for p, n in zip(probs, sizes):
+        outs.append(buf[off:off + p[4] * p[5]].view(p[4], p[5]))
+        off += n
+    lib = L.load()
+    live = [i for i, p in enumerate(probs) if p[4] and p[5] and p[6]]
+    for c0 in range(0, len(live), L.GEMM_MAX_GROUP):
+        idx = live[c0:c0 + L.GEMM_MAX_GROUP]
+        arr = (L.GemmProblem * len(idx))()
+        fl = by = 0.0
+        for k, i in enumerate(idx):
+            l, ldl, r, ldr, M, N, K, b = probs[i]
+            arr[k] = L.GemmProblem(l.data_ptr(), ldl, r.data_ptr(), ldr, outs[i].data_ptr(), N,
+                                   None if b is None else b.data_ptr(), M, N, K)
+            fl += 2.0 * M * N * K
+            by += 4.0 * (M * K + N * K + M * N)
+        with _Span("gemm_store_kernel", fl, by,
+                   detail="grouped %s x%d %s" % (kind, len(idx), " ".join("%dx%dx%d" % probs[i][4:7] for i in idx))):
+            L.check(lib.dssvae_gemm_f32_grouped(arr, len(idx), ta, tb, L.stream()), "dssvae_gemm_f32_grouped")
+    return outs
+
+
 def colsum(x, out=None, accumulate=False):
     x, ldx = _rows(_f32(x))
     M, N = x.shape
@@ -185,6 +230,51 @@ class _LinearFn(Function):
 
 def linear(x, w, b=None):
     return _LinearFn.apply(x, w, b)
+
+
+class _LinearManyFn(Function):
+    """several independent nn.Linear in grouped launches (forward, dgrad and wgrad each): tensors =
+    (x_0, w_0, b_0, x_1, w_1, b_1, ...); every b_i is a tensor (GRU input projections always have one)."""
+
+    @staticmethod
+    def forward(ctx, *tensors):
+        ctx.set_materialize_grads(False)
+        xs, ws, bs = tensors[0::3], tensors[1::3], tensors[2::3]
+        L.require_cuda(*xs)
+        x2 = [x.reshape(-1, x.size(-1)) for x in xs]
+        outs = _gemm_grouped("nt", list(zip(x2, ws)), biases=[b.contiguous() for b in bs])
+        ctx.save_for_backward(*x2, *ws)
+        ctx.n = len(xs)
+        ctx.xshapes = [x.shape for x in xs]
+        return tuple(o.view(*x.shape[:-1], w.size(0)) for o, x, w in zip(outs, xs, ws))
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n = ctx.n
+        saved = ctx.saved_tensors
+        x2, ws = saved[:n], saved[n:]
+        need = ctx.needs_input_grad
+        dy2 = [None if dy is None else dy.reshape(-1, dy.size(-1)).contiguous() for dy in dys]
+        ix = [i for i in range(n) if dy2[i] is not None and need[3 * i]]
+        iw = [i for i in range(n) if dy2[i] is not None and need[3 * i + 1]]
+        dxs = dict(zip(ix, _gemm_grouped("nn", [(dy2[i], ws[i]) for i in ix]))) if ix else {}
+        dws = dict(zip(iw, _gemm_grouped("tn", [(dy2[i], x2[i]) for i in iw]))) if iw else {}
+        out = []
+        for i in range(n):
+            dx = dxs[i].view(ctx.xshapes[i]) if i in dxs else None
+            db = colsum(dy2[i]) if (dy2[i] is not None and need[3 * i + 2]) else None
+            out += [dx, dws.get(i), db]
+        return tuple(out)
+
+
+def linear_many(triples):
+    """[(x, w, b), ...] -> [x @ w^T + b, ...]; the products share grouped launches."""
+    if len(triples) == 1:
+        return [linear(*triples[0])]
+    flat = []
+    for x, w, b in triples:
+        flat += [x, w, b]
+    return list(_LinearManyFn.apply(*flat))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -789,6 +879,13 @@ class _GruFn(Function):
             _note_persistent_error(wsb)
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
+        # recurrent weight gradients dW_hh = dgh^T . h_{t-1} of all instances in grouped launches
+        iw = [i for i in range(n) if dgx[i] is not None and ctx.needs_input_grad[2 + 4 * i]]
+        pairs = []
+        for i in iw:
+            rows = BT[i][0] * BT[i][1]
+            pairs.append((dgh[i].view(rows, 3 * Hs[i]), gates[i].view(rows, 5 * Hs[i])[:, 4 * Hs[i]:]))
+        dws = dict(zip(iw, _gemm_grouped("tn", pairs))) if iw else {}
         out = [None]
         for i in range(n):
             if dgx[i] is None:
@@ -798,9 +895,8 @@ class _GruFn(Function):
             H = Hs[i]
             rows = BT[i][0] * BT[i][1]
             g2 = dgh[i].view(rows, 3 * H)
-            dw = mm_tn(g2, gates[i].view(rows, 5 * H)[:, 4 * H:]) if need[1] else None
             db = colsum(g2) if need[2] else None
-            out += [dgx[i] if need[0] else None, dw, db, dh0[i] if (need[3] and not ctx.h0_none[i]) else None]
+            out += [dgx[i] if need[0] else None, dws.get(i), db, dh0[i] if (need[3] and not ctx.h0_none[i]) else None]
         return tuple(out)
 
 

@@ -54,6 +54,22 @@ int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64
                            float* C, int64_t ldc, const float* bias,
                            int M, int N, int K, float alpha, float beta, int ksplit, void* stream);
 
+/* Up to DSSVAE_GEMM_MAX_GROUP independent products of ONE layout (trans_a, trans_b as above) in one
+ * launch: C_i += A_i . B_i^T + bias_i (alpha = 1; the caller zero-fills C_i for a plain product).
+ * Same reference call sites as dssvae_gemm_f32: the per-direction / per-head input projections of
+ * nn.GRU and their weight gradients (encoder/rnn_encoder.py:52, decoder/rnn_decoder.py:65), which
+ * are too small to fill the chip one at a time. */
+#define DSSVAE_GEMM_MAX_GROUP 8
+typedef struct {
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
+    float* C; int64_t ldc;
+    const float* bias;
+    int32_t M, N, K;
+} dssvae_gemm_problem;
+int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* problems_host, int n, int trans_a, int trans_b,
+                            void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused vocabulary projection + online log-sum-exp (logits are never written).
  *   logit[m,n] = Xh[m,:Kh] . W[n,:Kh] + Xe[m,:Ke] . W[n,Kh:Kh+Ke] + bias[n]
