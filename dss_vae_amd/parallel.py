@@ -41,8 +41,9 @@ class GradBuckets(object):
     fixed order whatever order autograd fires the hooks in (RCCL requires identical issue order on
     every rank; the fired sets are identical on all ranks because the graphs are).  A gradient that
     arrives for a bucket that is already on the wire cannot be repaired and raises.  `finish()` sends
-    whatever has not been sent (parameters that got no gradient still take part: their slice holds
-    zeros on every rank) and makes the averaged gradients visible to the current stream.
+    whatever has not been sent and makes the averaged gradients visible to the current stream.  A bucket
+    none of whose parameters got a gradient in the last step of this kind is not sent at all (its slice
+    is zero on every rank).
     """
 
     def __init__(self, flat_grad, params, offsets, bucket_elems, group=None, overlap=True):
@@ -70,12 +71,15 @@ class GradBuckets(object):
             for i in idx:
                 self.bucket_of[i] = b
         self.expected = {}  # tag -> frozenset of parameter indices that fired in the last step of that kind
+        self.known, self.skipped = None, 0
         self.sent_early = 0  # buckets sent from hooks in the last step (observability / tests)
         self.reset()
 
     def reset(self, tag="main"):
         self.tag = tag
-        self.expect = self.expected.get(tag) if self.overlap else None
+        self.known = self.expected.get(tag)            # parameters that fired in the last step of this kind
+        self.expect = self.known if self.overlap else None
+        self.skipped = 0   # buckets not sent at all in this step (observability / tests)
         self.fired = set()
         if self.expect is not None:
             self.pending = [sum(1 for i in idx if i in self.expect) for _, _, idx in self.buckets]
@@ -84,7 +88,15 @@ class GradBuckets(object):
         self.sent_early = 0
 
     def _send(self, b):
-        lo, hi, _ = self.buckets[b]
+        lo, hi, idx = self.buckets[b]
+        if self.known is not None and not any(i in self.known for i in idx):
+            # no parameter of this bucket gets a gradient in this kind of step (frozen adversaries in a main
+            # pass -- 60 % of the buffer at V = 30k -- or everything but the adversaries in a discriminator
+            # pass): its slice is zero on every rank, the average is zero, nothing to send.  The fired sets
+            # are identical on all ranks, so all ranks skip the same buckets; a gradient that does show up
+            # for a skipped bucket raises in mark_ready like one for a bucket already on the wire.
+            self.skipped += 1
+            return
         chunk = self.flat[lo:hi]
         if self.comm is not None:
             self.comm.wait_stream(torch.cuda.current_stream())
@@ -109,6 +121,12 @@ class GradBuckets(object):
     def mark_ready(self, i):
         self.fired.add(i)
         if self.expect is None:
+            if self.known is not None and i not in self.known and \
+                    not any(k in self.known for k in self.buckets[self.bucket_of[i]][2]):
+                raise RuntimeError(
+                    "gradient of parameter %d arrived for a bucket that this kind of step (tag %r) does not "
+                    "all-reduce: the autograd graph differs from the previous one; give the steps different tags"
+                    % (i, self.tag))
             return
         b = self.bucket_of[i]
         if b < self.next:
