@@ -32,6 +32,7 @@ PEAK_HBM_GBS = 8000.0         # HBM3E spec; ~6.3 TB/s achievable
 
 KERNEL_BOUND = {
     "linear_lse_kernel": "mfma", "linear_dlogits_kernel": "mfma", "gemm_store_kernel": "mfma",
+    "gemm_group_kernel": "mfma",
     "gru_fwd_kernel": "hbm", "gru_bwd_kernel": "hbm", "adam_kernel": "hbm",
 }
 

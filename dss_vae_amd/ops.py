@@ -184,7 +184,7 @@ def _gemm_grouped(kind, pairs, biases=None):
                                    None if b is None else b.data_ptr(), M, N, K)
             fl += 2.0 * M * N * K
             by += 4.0 * (M * K + N * K + M * N)
-        with _Span("gemm_store_kernel", fl, by,
+        with _Span("gemm_group_kernel", fl, by,
                    detail="grouped %s x%d %s" % (kind, len(idx), " ".join("%dx%dx%d" % probs[i][4:7] for i in idx))):
             L.check(lib.dssvae_gemm_f32_grouped(arr, len(idx), ta, tb, L.stream()), "dssvae_gemm_f32_grouped")
     return outs
