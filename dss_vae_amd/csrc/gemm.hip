@@ -46,14 +46,24 @@ template <bool TA, bool TB, int WM, int WN>
 constexpr int lds_floats() { return 2 * (img_floats(TA, 64 * WM) + img_floats(TB, 64 * WN)); }
 
 // ---- global -> register -> LDS staging of one operand tile (R rows x 32 k) -----------------------
-template <bool TRANS, bool VEC, int R>
+// VW = vector width of the global loads / LDS stores: 4 (16-byte granules), 2 (8-byte granules: leading
+// dimensions and extents that are even but not multiples of 4 -- the 3H = 450 gate rows of the default
+// encoder) or 1 (scalar, any shape).  A granule is entirely in or out of range by the host's choice of VW.
+template <int VW> struct VecT;
+template <> struct VecT<4> { typedef float4 T; static __device__ __forceinline__ T zero() { return make_float4(0.f, 0.f, 0.f, 0.f); } };
+template <> struct VecT<2> { typedef float2 T; static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); } };
+template <> struct VecT<1> { typedef float T; static __device__ __forceinline__ T zero() { return 0.f; } };
+
+template <bool TRANS, int VW, int R>
 struct Stager {
-    static constexpr int NV = R * BK / 1024;  // float4 per thread (VEC)
+    static constexpr bool VEC = VW > 1;
+    typedef typename VecT<VW>::T V;
+    static constexpr int NV = R * BK / (NTHREADS * (VEC ? VW : 4));  // granules per thread (VEC)
     static constexpr int NS = R * BK / 256;   // floats per thread (scalar)
-    static constexpr int TPR = BK / 4;        // k-contiguous image: threads per row (VEC)
+    static constexpr int TPR = BK / (VEC ? VW : 4);   // k-contiguous image: threads per row (VEC)
     static constexpr int RPP = NTHREADS / TPR;   // rows per pass (VEC)
     static constexpr int RPS = NTHREADS / BK;    // rows per pass (scalar)
-    float4 v[VEC ? NV : 1];
+    V v[VEC ? NV : 1];
     float s[VEC ? 1 : NS];
     const float* b1[(!TRANS && VEC) ? NV : 1];
     const float* b2[(!TRANS && VEC) ? NV : 1];
@@ -81,14 +91,14 @@ struct Stager {
     // the MFMAs of a k-group (one part per MFMA sub-step): item i belongs to part i*4/N.
     static constexpr int NITEM = VEC ? NV : NS;
     static constexpr __host__ __device__ bool in_part(int i, int part) { return (i * 4) / NITEM == part; }
-    const float* lbase;   // !TRANS scalar / TRANS: unused
     int loff;             // !TRANS: column offset inside the chosen panel
     bool lfirst;
+    int lk0;
 
     // per-tile scalars of the load (k range check, panel choice); resets okmask
     __device__ __forceinline__ void begin_load(int k0) {
         if (!TRANS) {
-            const int k = k0 + (VEC ? 4 * (int)(threadIdx.x % TPR) : (int)(threadIdx.x % BK));
+            const int k = k0 + (VEC ? VW * (int)(threadIdx.x % TPR) : (int)(threadIdx.x % BK));
             const bool ok = k < K;
             const int kc = ok ? k : 0;
             lfirst = kc < K1;
@@ -99,14 +109,13 @@ struct Stager {
         }
         lk0 = k0;
     }
-    int lk0;
 
     __device__ __forceinline__ void load_part(int part) {
         if (!TRANS) {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (in_part(i, part)) v[i] = *reinterpret_cast<const float4*>((lfirst ? b1[i] : b2[i]) + loff);
+                    if (in_part(i, part)) v[i] = *reinterpret_cast<const V*>((lfirst ? b1[i] : b2[i]) + loff);
             } else {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
@@ -118,16 +127,16 @@ struct Stager {
             }
         } else {
             if (VEC) {
-                constexpr int TPK = R / 4;          // threads per k row
+                constexpr int TPK = R / VW;          // threads per k row
                 constexpr int KSTEP = NTHREADS / TPK;
-                const int r4 = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
+                const int rv = min(r0 + VW * (int)(threadIdx.x % TPK), Rtot - VW);
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (in_part(i, part)) {
                         const int k = lk0 + (int)(threadIdx.x / TPK) + KSTEP * i;
                         const bool ok = k < K;
                         okmask |= ok ? (1u << i) : 0u;
-                        v[i] = *reinterpret_cast<const float4*>(p1 + (int64_t)(ok ? k : 0) * ld1 + r4);
+                        v[i] = *reinterpret_cast<const V*>(p1 + (int64_t)(ok ? k : 0) * ld1 + rv);
                     }
             } else {
                 constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
@@ -156,8 +165,8 @@ struct Stager {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (in_part(i, part))
-                        *reinterpret_cast<float4*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + 4 * (threadIdx.x % TPR)) =
-                            okmask ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<V*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + VW * (threadIdx.x % TPR)) =
+                            okmask ? v[i] : VecT<VW>::zero();
             } else {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
@@ -166,13 +175,13 @@ struct Stager {
             }
         } else {
             if (VEC) {
-                constexpr int TPK = R / 4;
+                constexpr int TPK = R / VW;
                 constexpr int KSTEP = NTHREADS / TPK;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (in_part(i, part))
-                        *reinterpret_cast<float4*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + 4 * (threadIdx.x % TPK)) =
-                            ((okmask >> i) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                        *reinterpret_cast<V*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + VW * (threadIdx.x % TPK)) =
+                            ((okmask >> i) & 1u) ? v[i] : VecT<VW>::zero();
             } else {
                 constexpr int KSTEP = NTHREADS / R;
 #pragma unroll
@@ -203,7 +212,7 @@ __device__ __forceinline__ void read_frag(float (&f)[4], const float* img, int r
 }
 
 // ---- one (64*WM) x (64*WN) output tile over k-tiles [kt0, kt1) -----------------------------------
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M, int N, int K, int m0, int n0,
                                               int kt0, int kt1, float* lds, f32x16 (&acc)[WM][WN]) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -220,8 +229,8 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Stager<TA, VEC, BM> sa;
-    Stager<TB, VEC, BN> sb;
+    Stager<TA, VW, BM> sa;
+    Stager<TB, VW, BN> sb;
     sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K);
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
@@ -364,7 +373,7 @@ __device__ __forceinline__ void tile_to_global(const f32x16 (&acc)[WM][WN], floa
 }
 
 // ---- STORE ---------------------------------------------------------------------------------------
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
                                                 const float* __restrict__ bias, int M, int N, int K, float alpha,
                                                 float beta, int tiles_n, int ksplit, int kt_per_split, int cvec,
@@ -376,7 +385,7 @@ __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, floa
     const int kt0 = ks * kt_per_split, kt1 = min(nk, kt0 + kt_per_split);
     if (kt0 >= kt1) return;
     f32x16 acc[WM][WN];
-    tile_mainloop<TA, TB, VEC, WM, WN>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
+    tile_mainloop<TA, TB, VW, WM, WN>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
     if (ksplit > 1) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
@@ -406,14 +415,14 @@ __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, floa
     tile_to_global<WM, WN>(acc, lds, C, ldc, m0, n0, M, N, beta, cvec != 0);
 }
 
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
                                                                const float* __restrict__ bias, int M, int N, int K,
                                                                float alpha, float beta, int tiles_n, int ntiles,
                                                                int ksplit, int kt_per_split, int cvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
-    store_tile_body<TA, TB, VEC, WM, WN>(a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ksplit, kt_per_split, cvec,
+    store_tile_body<TA, TB, VW, WM, WN>(a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ksplit, kt_per_split, cvec,
                                          wid, lds);
 }
 
@@ -430,13 +439,13 @@ struct GroupArgs {
     int n;
 };
 
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 __global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.p[i + 1].wg_begin) ++i;
     const GroupProblem& q = g.p[i];
-    store_tile_body<TA, TB, VEC, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 1.f, q.tiles_n, q.ksplit,
+    store_tile_body<TA, TB, VW, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 1.f, q.tiles_n, q.ksplit,
                                          q.ktps, q.cvec, (int)blockIdx.x - q.wg_begin, lds);
 }
 
@@ -472,7 +481,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x16 acc[2][2];
-        tile_mainloop<false, false, VEC, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
+        tile_mainloop<false, false, VEC ? 4 : 1, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
         // logits (+bias; columns past N masked) -> LDS image [128][132]
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, 
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     f32x16 acc[2][2];
-    tile_mainloop<false, false, VEC, 2, 2>(a, b, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
+    tile_mainloop<false, false, VEC ? 4 : 1, 2, 2>(a, b, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
     const int c0 = n0 + acc_col<2>(0), c1 = n0 + acc_col<2>(1);
     const bool ok0 = c0 < N, ok1 = c1 < N;
     const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
@@ -707,6 +716,15 @@ void allow_lds(F* func, int bytes) {
 
 bool vec_ok(const float* p, int64_t ld) { return p == nullptr || (aligned16(p) && (ld % 4) == 0); }
 
+// widest granule (4, 2 or 1 floats) that every load of an operand can use: base alignment, leading dimension
+// and the extent the granules run along (K for a k-contiguous operand, the row count for a transposed one)
+int operand_vw(const float* p, int64_t ld, bool trans, int rows, int K) {
+    const int ext = trans ? rows : K;
+    for (int vw = 4; vw > 1; vw >>= 1)
+        if ((reinterpret_cast<uintptr_t>(p) % (4 * vw)) == 0 && (ld % vw) == 0 && (ext % vw) == 0 && ext >= vw) return vw;
+    return 1;
+}
+
 OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, bool* vec) {
     OpA a;
     a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr;
@@ -757,7 +775,7 @@ StorePlan plan_store(int M, int N, int K, int bn, bool may_split) {
     return best;
 }
 
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                  float alpha, float beta, int ksplit_req, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -774,7 +792,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
         if (e != DSSVAE_OK) return e;
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
-    auto kern = gemm_store_kernel<TA, TB, VEC, WM, WN>;
+    auto kern = gemm_store_kernel<TA, TB, VW, WM, WN>;
     allow_lds(kern, lds_bytes);
     const int cvec = aligned16(C) && (ldc % 4) == 0 && (N % 4) == 0;
     hipLaunchKernelGGL(kern, dim3(ntiles * ksplit), dim3(NTHREADS), lds_bytes, s, a, b, C, ldc, bias, M, N, K, alpha,
@@ -783,7 +801,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     return DSSVAE_OK;
 }
 
-template <bool TA, bool TB, bool VEC>
+template <bool TA, bool TB, int VW>
 int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                       float alpha, float beta, int ksplit, hipStream_t s) {
     // tile width (128x128 or 128x64) by the cost model above
@@ -792,8 +810,8 @@ int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const f
     const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width
     if (force == 64) narrow = true;
     if (force == 128) narrow = false;
-    if (narrow) return launch_store<TA, TB, VEC, 2, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
-    return launch_store<TA, TB, VEC, 2, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
+    if (narrow) return launch_store<TA, TB, VW, 2, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
+    return launch_store<TA, TB, VW, 2, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
 }
 
 }  // namespace
@@ -817,14 +835,15 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
     a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows;
     OpB b;
     b.p = B; b.ld = ldb;
-    // fast path: every float4 granule of both operands is aligned and entirely in or out of range
-    const bool va = vec_ok(A, lda) && (trans_a ? (M % 4 == 0 && M >= 4) : (K % 4 == 0));
-    const bool vb = vec_ok(B, ldb) && (trans_b ? (N % 4 == 0 && N >= 4) : (K % 4 == 0));
-    const bool vec = va && vb;
+    // widest granule both operands allow: every granule is aligned and entirely in or out of range
+    const int vw = min(operand_vw(A, lda, trans_a != 0, M, K), operand_vw(B, ldb, trans_b != 0, N, K));
     hipStream_t s = (hipStream_t)stream;
-#define GO(TA, TB)                                                                                              \
-    return vec ? launch_store_tile<TA, TB, true>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)          \
-               : launch_store_tile<TA, TB, false>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s)
+#define GO(TA, TB)                                                                                                  \
+    do {                                                                                                            \
+        if (vw == 4) return launch_store_tile<TA, TB, 4>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);      \
+        if (vw == 2) return launch_store_tile<TA, TB, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);      \
+        return launch_store_tile<TA, TB, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);                   \
+    } while (0)
     if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
     else { if (trans_b) GO(false, true); else GO(false, false); }
 #undef GO
@@ -832,7 +851,7 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
 
 namespace {
 
-template <bool TA, bool TB, bool VEC, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN>
 int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
     // one k-tile count per workgroup for the whole group (they finish together): the smallest that keeps
@@ -860,7 +879,7 @@ int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t
         wg += ((pr[i].M + BM - 1) / BM) * q.tiles_n * q.ksplit;
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
-    auto kern = gemm_group_kernel<TA, TB, VEC, WM, WN>;
+    auto kern = gemm_group_kernel<TA, TB, VW, WM, WN>;
     allow_lds(kern, lds_bytes);
     hipLaunchKernelGGL(kern, dim3(wg), dim3(NTHREADS), lds_bytes, s, g);
     DSSVAE_CHECK_LAUNCH();
@@ -873,7 +892,7 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
     if (!pr || n <= 0 || n > DSSVAE_GEMM_MAX_GROUP) return DSSVAE_EINVAL;
     GroupArgs g;
     g.n = n;
-    bool vec = true;
+    int vw = 4;
     int64_t padded128 = 0, padded64 = 0;
     for (int i = 0; i < n; ++i) {
         const dssvae_gemm_problem& x = pr[i];
@@ -885,9 +904,7 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
         q.C = x.C; q.ldc = x.ldc; q.bias = x.bias;
         q.M = x.M; q.N = x.N; q.K = x.K;
         q.cvec = aligned16(x.C) && (x.ldc % 4) == 0 && (x.N % 4) == 0;
-        const bool va = vec_ok(x.A, x.lda) && (trans_a ? (x.M % 4 == 0 && x.M >= 4) : (x.K % 4 == 0));
-        const bool vb = vec_ok(x.B, x.ldb) && (trans_b ? (x.N % 4 == 0 && x.N >= 4) : (x.K % 4 == 0));
-        vec = vec && va && vb;
+        vw = min(vw, min(operand_vw(x.A, x.lda, trans_a != 0, x.M, x.K), operand_vw(x.B, x.ldb, trans_b != 0, x.N, x.K)));
         const int64_t tm = (x.M + 127) / 128, nk = (x.K + BK - 1) / BK;
         padded128 += tm * ((x.N + 127) / 128) * nk * 1000;
         padded64 += tm * ((x.N + 63) / 64) * nk * 535;
@@ -896,10 +913,12 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
     hipStream_t s = (hipStream_t)stream;
 #define GO(TA, TB)                                                                                   \
     do {                                                                                             \
-        if (vec) return narrow ? launch_group<TA, TB, true, 2, 1>(g, pr, n, s)                       \
-                               : launch_group<TA, TB, true, 2, 2>(g, pr, n, s);                      \
-        return narrow ? launch_group<TA, TB, false, 2, 1>(g, pr, n, s)                               \
-                      : launch_group<TA, TB, false, 2, 2>(g, pr, n, s);                              \
+        if (vw == 4) return narrow ? launch_group<TA, TB, 4, 2, 1>(g, pr, n, s)                      \
+                                   : launch_group<TA, TB, 4, 2, 2>(g, pr, n, s);                     \
+        if (vw == 2) return narrow ? launch_group<TA, TB, 2, 2, 1>(g, pr, n, s)                      \
+                                   : launch_group<TA, TB, 2, 2, 2>(g, pr, n, s);                     \
+        return narrow ? launch_group<TA, TB, 1, 2, 1>(g, pr, n, s)                                   \
+                      : launch_group<TA, TB, 1, 2, 2>(g, pr, n, s);                                  \
     } while (0)
     if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
     else { if (trans_b) GO(false, true); else GO(false, false); }

@@ -41,6 +41,42 @@ def test_gemm_all_layouts(M, N, K):
     close(out, xv.cpu().double() @ w.double().t() + 1.0, what="nt beta view")
 
 
+def test_gemm_grouped_and_linear_many():
+    """several independent products per launch (dssvae_gemm_f32_grouped), mixed shapes incl. the 3H = 450 /
+    H = 150 extents of the default encoder (8-byte granules), and the autograd wrapper built on it"""
+    from dss_vae_amd import ops
+    shapes = [(7680 // 8, 450, 300), (960, 450, 300), (130, 257, 70), (64, 100, 600), (300, 1800, 300), (5, 7, 3)]
+    xs = [rnd(M, K, seed=10 + i) for i, (M, N, K) in enumerate(shapes)]
+    ws = [rnd(N, K, seed=30 + i) for i, (M, N, K) in enumerate(shapes)]
+    bs = [rnd(N, seed=50 + i) for i, (M, N, K) in enumerate(shapes)]
+    dys = [rnd(M, N, seed=70 + i) for i, (M, N, K) in enumerate(shapes)]
+    xd, wd, bd, dyd = ([t.to(DEV) for t in ts] for ts in (xs, ws, bs, dys))
+    for got, x, w, b in zip(ops._gemm_grouped("nt", list(zip(xd, wd)), biases=bd), xs, ws, bs):
+        close(got, x.double() @ w.double().t() + b.double(), what="grouped nt")
+    for got, dy, w in zip(ops._gemm_grouped("nn", list(zip(dyd, wd))), dys, ws):
+        close(got, dy.double() @ w.double(), what="grouped nn")
+    for got, dy, x in zip(ops._gemm_grouped("tn", list(zip(dyd, xd))), dys, xs):
+        close(got, dy.double().t() @ x.double(), what="grouped tn")
+    # autograd: shared input, one frozen weight
+    leaves = [[t.clone().double().requires_grad_(True) for t in (xs[0], ws[0], bs[0])],
+              [None, ws[1].clone().double().requires_grad_(True), bs[1].clone().double().requires_grad_(True)]]
+    ref = [leaves[0][0] @ leaves[0][1].t() + leaves[0][2], leaves[0][0] @ leaves[1][1].t() + leaves[1][2]]
+    (ref[0] * dys[0].double()).sum().backward(retain_graph=True)
+    (ref[1] * dys[1].double()).sum().backward()
+    x0 = xs[0].clone().to(DEV).requires_grad_(True)
+    w0, b0 = ws[0].clone().to(DEV).requires_grad_(True), bs[0].clone().to(DEV).requires_grad_(True)
+    w1, b1 = ws[1].clone().to(DEV).requires_grad_(True), bs[1].clone().to(DEV).requires_grad_(True)
+    o0, o1 = ops.linear_many([(x0, w0, b0), (x0, w1, b1)])
+    close(o0, ref[0], what="many out0")
+    close(o1, ref[1], what="many out1")
+    ((o0 * dyd[0]).sum() + (o1 * dyd[1]).sum()).backward()
+    close(x0.grad, leaves[0][0].grad, rtol=1e-4, atol=1e-5, what="many dx (summed over both uses)")
+    close(w0.grad, leaves[0][1].grad, rtol=1e-4, atol=1e-5, what="many dw0")
+    close(w1.grad, leaves[1][1].grad, rtol=1e-4, atol=1e-5, what="many dw1")
+    close(b0.grad, leaves[0][2].grad, rtol=1e-4, atol=1e-5, what="many db0")
+    close(b1.grad, leaves[1][2].grad, rtol=1e-4, atol=1e-5, what="many db1")
+
+
 def test_gemm_row_gather():
     from dss_vae_amd import ops
     tab, w = rnd(50, 24, seed=1).to(DEV), rnd(36, 24, seed=2).to(DEV)
