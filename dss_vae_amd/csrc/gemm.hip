@@ -469,8 +469,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
     static_assert(BM * LDT <= lds_floats<false, false, 2, 2>(), "tile image must fit in the operand buffers");
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
     const int m0 = mb * BM;
-    const int t_begin = split * tiles_per_split;
-    const int t_end = min(t_begin + tiles_per_split, tiles_n);
+    // column tiles dealt evenly: the first tiles_n % n_split splits take one tile more than the others
+    // (tiles_per_split = tiles_n / n_split, rounded down): no split is more than one tile longer than another
+    const int rem = tiles_n - tiles_per_split * n_split;
+    const int t_begin = split * tiles_per_split + min(split, rem);
+    const int t_end = t_begin + tiles_per_split + (split < rem ? 1 : 0);
     const int nk = (K + BK - 1) / BK;
     const int col = 4 * (threadIdx.x % TPR), rbase = threadIdx.x / TPR;
     float rm[NR], rs[NR];
@@ -941,7 +944,7 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
     vec = vec && vec_ok(W, ldw);
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
     if (n_split > tiles_n) return DSSVAE_EINVAL;
-    const int tps = (tiles_n + n_split - 1) / n_split;
+    const int tps = tiles_n / n_split;  // rounded down: the kernel deals the remainder one tile each
     hipStream_t s = (hipStream_t)stream;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
     const int lvec = logits && aligned16(logits) && (ldl % 4) == 0 && (N % 4) == 0;

@@ -373,12 +373,10 @@ def reparam_kl(mean, logv, eps):
 # Fused vocabulary projection + cross-entropy
 # ----------------------------------------------------------------------------------------------
 def _pick_split(M, N):
-    """column splits of the LSE kernel: about two workgroups per CU (its occupancy), every split the same
-    number of 128-column tiles (the kernel lasts as long as its longest split)"""
+    """column splits of the LSE kernel: about two workgroups per CU (its occupancy); the kernel deals the
+    128-column tiles evenly over the splits (no split more than one tile longer than another)"""
     tiles_m, tiles_n = (M + 127) // 128, (N + 127) // 128
-    s = max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
-    per = (tiles_n + s - 1) // s
-    return (tiles_n + per - 1) // per
+    return max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
 
 
 def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None):
