@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
 
 // ---- grouped STORE: up to DSSVAE_GEMM_MAX_GROUP independent products of one layout in ONE launch ----
 // (the per-direction / per-head GRU projections and weight gradients are 1-3 GFLOP each: alone they
-// cannot fill the chip and pay a launch + a tail each).  C += A.B^T + bias: the caller zero-fills C.
+// cannot fill the chip and pay a launch + a tail each).  C = A.B^T + bias.
 struct GroupProblem {
     OpA a; OpB b;
     float* C; int64_t ldc; const float* bias;
@@ -445,7 +445,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
     int i = 0;
     while (i + 1 < g.n && (int)blockIdx.x >= g.p[i + 1].wg_begin) ++i;
     const GroupProblem& q = g.p[i];
-    store_tile_body<TA, TB, VW, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 1.f, q.tiles_n, q.ksplit,
+    // one workgroup per tile: plain store; split K: fp32 atomics into the C the host has zero-filled
+    store_tile_body<TA, TB, VW, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, q.tiles_n, q.ksplit,
                                          q.ktps, q.cvec, (int)blockIdx.x - q.wg_begin, lds);
 }
 
@@ -880,6 +881,10 @@ int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t
         q.ksplit = (nk + q.ktps - 1) / q.ktps;
         q.wg_begin = wg;
         wg += ((pr[i].M + BM - 1) / BM) * q.tiles_n * q.ksplit;
+        if (q.ksplit > 1) {
+            const int e = dssvae_zero2d(q.C, q.ldc, q.M, q.N, s);
+            if (e != DSSVAE_OK) return e;
+        }
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
     auto kern = gemm_group_kernel<TA, TB, VW, WM, WN>;

@@ -299,6 +299,9 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     __syncthreads();
 
     const float* Wl = Ws + kq * 16 + j;
+    // bias gradients (column sums of dgx / dgh over batch and time) ride along in registers
+    float sb_r[4] = {0.f, 0.f, 0.f, 0.f}, sb_z[4] = {0.f, 0.f, 0.f, 0.f}, sb_n[4] = {0.f, 0.f, 0.f, 0.f},
+          sb_m[4] = {0.f, 0.f, 0.f, 0.f};
     for (int step = 0; step < T; ++step) {
         // backward walks the forward order in reverse
         const int fstep = T - 1 - step;
@@ -338,6 +341,8 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         }
         // this slice's three gate blocks (pad units / pad rows publish zeros); hand over first, the
         // dgx / dgh history stores then overlap the wait
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sb_r[c] += dgr[c]; sb_z[c] += dgz[c]; sb_n[c] += dgn[c]; sb_m[c] += dgm[c]; }
         st_sc1((f32x4){dgr[0], dgr[1], dgr[2], dgr[3]}, rcur, voff, own);
         st_sc1((f32x4){dgz[0], dgz[1], dgz[2], dgz[3]}, rcur, voff, own + BLK * 4);
         st_sc1((f32x4){dgm[0], dgm[1], dgm[2], dgm[3]}, rcur, voff, own + 2 * BLK * 4);
@@ -377,6 +382,32 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + acc[0][c] + acc[1][c] + acc[2][c];
     }
     if (row_ok && n_ok > 0 && in.dh0) store4(in.dh0 + (size_t)b * H + ub, dh, vec_h, n_ok);
+    if (in.dbias_x || in.dbias_h) {
+        // sum over the 16 batch rows of the wave (lanes with the same unit quad), then one atomic per unit
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) {
+                sb_r[c] += __shfl_xor(sb_r[c], o, 64); sb_z[c] += __shfl_xor(sb_z[c], o, 64);
+                sb_n[c] += __shfl_xor(sb_n[c], o, 64); sb_m[c] += __shfl_xor(sb_m[c], o, 64);
+            }
+        }
+        if (j == 0) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (c < n_ok) {
+                    const int u = ub + c;
+                    if (in.dbias_x) {
+                        atomicAdd(in.dbias_x + u, sb_r[c]); atomicAdd(in.dbias_x + H + u, sb_z[c]);
+                        atomicAdd(in.dbias_x + 2 * H + u, sb_n[c]);
+                    }
+                    if (in.dbias_h) {
+                        atomicAdd(in.dbias_h + u, sb_r[c]); atomicAdd(in.dbias_h + H + u, sb_z[c]);
+                        atomicAdd(in.dbias_h + 2 * H + u, sb_m[c]);
+                    }
+                }
+        }
+    }
 }
 
 struct Layout {

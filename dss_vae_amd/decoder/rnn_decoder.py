@@ -159,8 +159,8 @@ def score_many(jobs):
             h0 = j["h0"][layer]
             if ng:
                 whh, bhh, h0 = whh.detach(), bhh.detach(), h0.detach()
-            proj[ng].append((k, (x, wih, bih)))
-            insts.append(dict(whh=whh, bhh=bhh, h0=h0, group=k, col=0, save=not ng))
+            proj[ng].append((k, (x, wih, bih.detach())))  # b_ih's gradient comes out of the recurrence's backward
+            insts.append(dict(whh=whh, bhh=bhh, bih=None if ng else bih, h0=h0, group=k, col=0, save=not ng))
         # the input projections of all heads of the layer share grouped MFMA launches (evaluation-only
         # heads in a group of their own, outside autograd)
         for ng, items in proj.items():

@@ -59,8 +59,9 @@ def encode_many(encoders, input_var, input_lengths=None):
                 x = x * ops.dropout_mask(tuple(x.shape), e.rnn_droprate, GLOBAL_SEEDS.next(), dev)
             for di, suffix in enumerate(e.rnn.suffixes()):
                 wih, whh, bih, bhh = e.rnn.layer_params(layer, suffix)
-                proj.append((x, wih, bih))
-                insts.append(dict(whh=whh, bhh=bhh, h0=None, reverse=di == 1, group=ei, col=di * e.hidden_size))
+                proj.append((x, wih, bih.detach()))  # b_ih's gradient comes out of the recurrence's backward
+                insts.append(dict(whh=whh, bhh=bhh, bih=bih, h0=None, reverse=di == 1, group=ei,
+                                  col=di * e.hidden_size))
         # the input projections of every direction / encoder of the layer share grouped MFMA launches
         for inst, xp in zip(insts, ops.linear_many(proj)):
             inst["xproj"] = xp

@@ -30,7 +30,8 @@ class GruBwdInst(C.Structure):
     _fields_ = [("whh", C.c_void_p), ("h0", C.c_void_p), ("lengths", C.c_void_p), ("out", C.c_void_p),
                 ("ldo", C.c_int64), ("gates", C.c_void_p), ("dout", C.c_void_p), ("ldd", C.c_int64),
                 ("dh_last", C.c_void_p), ("dgx", C.c_void_p), ("dgh", C.c_void_p), ("dh0", C.c_void_p),
-                ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32)]
+                ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
+                ("dbias_x", C.c_void_p), ("dbias_h", C.c_void_p)]
 
 
 GEMM_MAX_GROUP = 8

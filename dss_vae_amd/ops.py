@@ -148,7 +148,7 @@ def mm_tn(dy, x, out=None, beta=0.0):
 def _gemm_grouped(kind, pairs, biases=None):
     """kind 'nt': x[M,K] @ w[N,K]^T (+bias) | 'nn': dy[M,N] @ w[N,K] | 'tn': dy[M,N]^T @ x[M,K], for a list
     of (left, right) operand pairs, in as few launches as the group limit allows; -> list of outputs
-    (views of ONE zero-filled buffer: the grouped kernel accumulates)."""
+    (views of one buffer)."""
     ta, tb = {"nt": (0, 0), "nn": (0, 1), "tn": (1, 1)}[kind]
     probs = []
     for i, (l, r) in enumerate(pairs):
@@ -167,13 +167,16 @@ def _gemm_grouped(kind, pairs, biases=None):
     L.require_cuda(*[p[0] for p in probs])
     dev = probs[0][0].device
     sizes = [(p[4] * p[5] + 3) // 4 * 4 for p in probs]
-    buf = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
     outs, off = [], 0
     for p, n in zip(probs, sizes):
         outs.append(buf[off:off + p[4] * p[5]].view(p[4], p[5]))
         off += n
     lib = L.load()
     live = [i for i, p in enumerate(probs) if p[4] and p[5] and p[6]]
+    for i, p in enumerate(probs):
+        if i not in live and p[4] and p[5]:
+            outs[i].zero_()  # empty inner dimension
     for c0 in range(0, len(live), L.GEMM_MAX_GROUP):
         idx = live[c0:c0 + L.GEMM_MAX_GROUP]
         arr = (L.GemmProblem * len(idx))()
@@ -774,7 +777,7 @@ class _GruFn(Function):
     def forward(ctx, meta, *tensors):
         ctx.set_materialize_grads(False)
         n = meta["n"]
-        xs, ws, bs, h0s = tensors[0::4], tensors[1::4], tensors[2::4], tensors[3::4]
+        xs, ws, bs, h0s = tensors[0::5], tensors[1::5], tensors[2::5], tensors[3::5]  # [4::5]: b_ih, gradient routing only
         L.require_cuda(*xs)
         dev = xs[0].device
         BT = [(x.size(0), x.size(1)) for x in xs]
@@ -851,11 +854,21 @@ class _GruFn(Function):
             dgx[i] = torch.empty(BT[i][0], BT[i][1], 3 * Hs[i], device=dev, dtype=torch.float32)
             dgh[i] = torch.empty(BT[i][0], BT[i][1], 3 * Hs[i], device=dev, dtype=torch.float32)
             dh0[i] = torch.empty(BT[i][0], Hs[i], device=dev, dtype=torch.float32)
+        # bias gradients (column sums of dgx / dgh) are accumulated by the persistent kernel itself
+        need_bx = [i in live and ctx.needs_input_grad[5 + 5 * i] for i in range(n)]
+        need_bh = [i in live and ctx.needs_input_grad[3 + 5 * i] for i in range(n)]
+        dbx = [torch.zeros(3 * Hs[i], device=dev, dtype=torch.float32) if need_bx[i] else None for i in range(n)]
+        dbh = [torch.zeros(3 * Hs[i], device=dev, dtype=torch.float32) if need_bh[i] else None for i in range(n)]
         lib = L.load()
         for i in live:
             if not ctx.fit[i]:
                 _gru_steps_bwd(ws[i], gates[i], lengths, bool(meta["reverse"][i]), douts[meta["group"][i]],
                                meta["col"][i], dhl[i], dgx[i], dgh[i], dh0[i])
+                rows = BT[i][0] * BT[i][1]
+                if dbx[i] is not None:
+                    colsum(dgx[i].view(rows, 3 * Hs[i]), out=dbx[i])
+                if dbh[i] is not None:
+                    colsum(dgh[i].view(rows, 3 * Hs[i]), out=dbh[i])
         live_p = [i for i in live if ctx.fit[i]]
         for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live_p]):
             launch = [live_p[k] for k in launch_]
@@ -867,7 +880,8 @@ class _GruFn(Function):
                     gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
                     0 if do is None else do.size(2), None if dhl[i] is None else dhl[i].data_ptr(),
                     dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
-                    int(meta["reverse"][i]))
+                    int(meta["reverse"][i]), None if dbx[i] is None else dbx[i].data_ptr(),
+                    None if dbh[i] is None else dbh[i].data_ptr())
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
@@ -878,7 +892,7 @@ class _GruFn(Function):
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         # recurrent weight gradients dW_hh = dgh^T . h_{t-1} of all instances in grouped launches
-        iw = [i for i in range(n) if dgx[i] is not None and ctx.needs_input_grad[2 + 4 * i]]
+        iw = [i for i in range(n) if dgx[i] is not None and ctx.needs_input_grad[2 + 5 * i]]
         pairs = []
         for i in iw:
             rows = BT[i][0] * BT[i][1]
@@ -887,14 +901,11 @@ class _GruFn(Function):
         out = [None]
         for i in range(n):
             if dgx[i] is None:
-                out += [None, None, None, None]
+                out += [None, None, None, None, None]
                 continue
-            need = ctx.needs_input_grad[1 + 4 * i: 5 + 4 * i]
-            H = Hs[i]
-            rows = BT[i][0] * BT[i][1]
-            g2 = dgh[i].view(rows, 3 * H)
-            db = colsum(g2) if need[2] else None
-            out += [dgx[i] if need[0] else None, dws.get(i), db, dh0[i] if (need[3] and not ctx.h0_none[i]) else None]
+            need = ctx.needs_input_grad[1 + 5 * i: 6 + 5 * i]
+            out += [dgx[i] if need[0] else None, dws.get(i), dbh[i], dh0[i] if (need[3] and not ctx.h0_none[i]) else None,
+                    dbx[i]]
         return tuple(out)
 
 
@@ -902,7 +913,9 @@ def gru_layer(insts, lengths=None, save=None, check=False):
     """Run independent GRU recurrences in as few persistent launches as fit the chip.
 
     insts: list of dicts {xproj [B,T,3H] (may be a column view), whh [3H,H], bhh [3H], h0 [B,H] or None,
-    reverse: bool, group: int, col: int, save: bool (default: the `save` argument; False = forward-only
+    bih [3H] or None (NOT used in forward -- xproj already holds it: when given, the caller has computed xproj
+    with a detached b_ih and the gradient of b_ih, the column sums of d(xproj), comes from the recurrence's
+    backward kernel instead of a separate reduction pass), reverse: bool, group: int, col: int, save: bool (default: the `save` argument; False = forward-only
     instance, no history kept)}.  Instances of one group write disjoint column ranges
     [col, col+H) of that group's output [B,T,width].  lengths: int32 device tensor [B] or None.
     Returns (list of group outputs, list of per-instance final states)."""
@@ -921,7 +934,8 @@ def gru_layer(insts, lengths=None, save=None, check=False):
                 save=[bool(i.get("save", save)) for i in insts], check=check)
     flat = []
     for i in insts:
-        flat += [i["xproj"], i["whh"], i["bhh"], empty if i.get("h0") is None else i["h0"]]
+        flat += [i["xproj"], i["whh"], i["bhh"], empty if i.get("h0") is None else i["h0"],
+                 empty if i.get("bih") is None else i["bih"]]
     res = _GruFn.apply(meta, *flat)
     return list(res[:len(groups)]), list(res[len(groups):])
 

@@ -55,7 +55,8 @@ int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64
                            int M, int N, int K, float alpha, float beta, int ksplit, void* stream);
 
 /* Up to DSSVAE_GEMM_MAX_GROUP independent products of ONE layout (trans_a, trans_b as above) in one
- * launch: C_i += A_i . B_i^T + bias_i (alpha = 1; the caller zero-fills C_i for a plain product).
+ * launch: C_i = A_i . B_i^T + bias_i (alpha = 1, beta = 0; outputs whose K loop is split are zero-filled
+ * by the library first).
  * Same reference call sites as dssvae_gemm_f32: the per-direction / per-head input projections of
  * nn.GRU and their weight gradients (encoder/rnn_encoder.py:52, decoder/rnn_decoder.py:65), which
  * are too small to fill the chip one at a time. */
@@ -187,6 +188,9 @@ typedef struct {
     /* produced: dgx, dgh [B,T,3H] (grad wrt xproj / wrt W_hh h + b_hh), dh0 [B,H] */
     float* dgx; float* dgh; float* dh0;
     int32_t B, T, H, reverse;
+    /* optional, ACCUMULATED into (caller zero-fills): bias gradients [3H] = column sums of dgx / dgh over
+     * batch and time (grad of b_ih / b_hh), so that no separate reduction pass reads dgx / dgh again */
+    float* dbias_x; float* dbias_h;
 } dssvae_gru_bwd_inst;
 
 int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host);

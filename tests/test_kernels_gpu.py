@@ -262,8 +262,11 @@ def test_persistent_gru_forward_backward(B, T, H, I, packed, stepwise, monkeypat
     insts = []
     for d in range(2):
         wih, whh, bih, bhh, h0 = dl[d]
-        xp = ops.linear(xd, wih, bih)
-        insts.append(dict(xproj=xp, whh=whh, bhh=bhh, h0=h0, reverse=bool(d), group=0, col=d * H))
+        if d == 0:
+            insts.append(dict(xproj=ops.linear(xd, wih, bih), whh=whh, bhh=bhh, h0=h0, reverse=False, group=0, col=0))
+        else:  # b_ih's gradient routed through the recurrence's backward (column sums taken in the kernel)
+            insts.append(dict(xproj=ops.linear(xd, wih, bih.detach()), whh=whh, bhh=bhh, bih=bih, h0=h0, reverse=True,
+                              group=0, col=H))
     (out,), hl = ops.gru_layer(insts, lengths=len_d, check=True)
     close(out, ref_out, what="out")
     for d in range(2):
