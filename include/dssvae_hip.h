@@ -78,8 +78,8 @@ int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* problems_host, int n, int
  * max and sum(exp(logit - max)) of that split into part_max/part_sum [M, n_split]; with
  * want_argmax it also writes the split's best column into part_arg [M, n_split].
  * logits (may be NULL): side output, the logits of these M rows into a caller slab [M, ldl]
- * (the training path passes a row chunk sized to stay in the Infinity Cache and turns it into
- * dlogits in place with dssvae_softmax_grad_inplace, so backward never recomputes the projection).
+ * (the training path passes a row chunk of up to 512 MiB and turns it into dlogits in place with
+ * dssvae_softmax_grad_inplace, so backward never recomputes the projection).
  * Replaces: RNNDecoder.forward_step's `self.out(cat(output, embedded))` + F.log_softmax
  * (decoder/rnn_decoder.py:70-73,94) and the scorer Linear+LogSoftmax of the bag-of-words heads
  * (vae/enhance_syntax_vae.py:607-615).  Xe may be NULL (Ke = 0).
