@@ -448,7 +448,7 @@ class _LinearCEFn(Function):
       projection per chunk of vocabulary columns (4 GEMM passes per trainable head in total).
     * uniform=True (the caller guarantees that every row receives the SAME upstream gradient, true for
       every loss term of the DSS-VAE models: sums of per-token NLL scaled by constants): forward walks
-      row chunks; the LSE kernel also drops the chunk's logits into an Infinity-Cache-sized slab, which
+      row chunks; the LSE kernel also drops the chunk's logits into a reusable slab (SLAB_BYTES), which
       is turned into dlogits in place and consumed by the dgrad / wgrad GEMMs right away.  The
       gradients for upstream = 1 are kept and scaled in backward (dX per row, dW / db by the common
       factor): 3 GEMM passes per trainable head, 2 per frozen one.  fp32 MFMA (157 TFLOP/s) makes the
@@ -563,7 +563,7 @@ class _LinearCEFn(Function):
             if db is not None:
                 db.mul_(c)
             return dxh, dxe, dW, db, None, None, None
-        # general path: per chunk of vocabulary columns, recompute dlogits into an Infinity-Cache-sized
+        # general path: per chunk of vocabulary columns, recompute dlogits into a
         # slab [M, nc] (+ the bias gradient by column sums in the same kernel), subtract the one-hot part,
         # then dX += dL.W_chunk (dgrad, accumulating) and dW_chunk = dL^T.[xh|xe] (wgrad, written once)
         xh, xe, W, b, target, lse, cnt = ctx.saved_tensors
