@@ -82,7 +82,10 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     int rc;
 #define TRY(call) do { rc = (call); if (rc != DSSVAE_OK) return rc; } while (0)
     for (int t = 0; t < max_len; ++t) {
-        TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, w.tok, B, E, nullptr, w.x, E, stream));
+        // the arg-max of step t-1 went straight into tokens[t-1]: it is also this step's input (no per-step
+        // device-to-device copy: the runtime's blit path costs more than the step's kernels)
+        const int64_t* prev = t == 0 ? w.tok : tokens + (size_t)(t - 1) * B;
+        TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, prev, B, E, nullptr, w.x, E, stream));
         const float* in = w.x;
         int in_dim = E;
         for (int l = 0; l < L; ++l) {
@@ -102,9 +105,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
                                        w.psum, w.parg, 1, nullptr, 0, stream);
         }
         if (rc != DSSVAE_OK) return rc;
-        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, S, nullptr, w.tok, stream));
-        e = hipMemcpyAsync(tokens + (size_t)t * B, w.tok, (size_t)B * 8, hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return (int)e;
+        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, S, nullptr, tokens + (size_t)t * B, stream));
     }
 #undef TRY
     if (h_final) {
