@@ -15,7 +15,7 @@ struct Ws {
     float* psum;     // [B,S]
     int64_t* parg;   // [B,S]
     int64_t* tok;    // [B]
-    float* h;        // [L][B,H]
+    float* h;        // [2][L][B,H]  (ping-pong: the fused cell step writes h' beside h)
     size_t bytes;
 };
 
@@ -33,7 +33,7 @@ Ws carve(void* base, int B, int E, int H, int L, int S) {
     w.psum = reinterpret_cast<float*>(take((size_t)B * S * 4));
     w.parg = reinterpret_cast<int64_t*>(take((size_t)B * S * 8));
     w.tok = reinterpret_cast<int64_t*>(take((size_t)B * 8));
-    w.h = reinterpret_cast<float*>(take((size_t)L * B * H * 4));
+    w.h = reinterpret_cast<float*>(take((size_t)2 * L * B * H * 4));
     w.bytes = off;
     return w;
 }
@@ -80,6 +80,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.tok, sos_id, B);
     DSSVAE_CHECK_LAUNCH();
     int rc;
+    int cur[DSSVAE_DECODE_MAX_LAYERS] = {0, 0, 0, 0};  // which half of the ping-pong holds layer l's state
 #define TRY(call) do { rc = (call); if (rc != DSSVAE_OK) return rc; } while (0)
     for (int t = 0; t < max_len; ++t) {
         // the arg-max of step t-1 went straight into tokens[t-1]: it is also this step's input (no per-step
@@ -89,10 +90,20 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
         const float* in = w.x;
         int in_dim = E;
         for (int l = 0; l < L; ++l) {
-            float* hl = w.h + (size_t)l * B * H;
-            TRY(small_linear(in, in_dim, p->w_ih[l], p->b_ih[l], B, 3 * H, w.gi, stream));
-            TRY(small_linear(hl, H, p->w_hh[l], p->b_hh[l], B, 3 * H, w.gh, stream));
-            TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
+            float* hl = w.h + ((size_t)cur[l] * L + l) * B * H;
+            float* hn = w.h + ((size_t)(cur[l] ^ 1) * L + l) * B * H;
+            rc = dssvae_skinny_gru_step(in, in_dim, in_dim, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l], H, p->b_ih[l],
+                                        p->b_hh[l], B, hn, H, stream);
+            if (rc == DSSVAE_OK) {
+                cur[l] ^= 1;
+                hl = hn;
+            } else if (rc == DSSVAE_ETOOBIG) {  // outside the fused kernel's range: two products + the cell
+                TRY(small_linear(in, in_dim, p->w_ih[l], p->b_ih[l], B, 3 * H, w.gi, stream));
+                TRY(small_linear(hl, H, p->w_hh[l], p->b_hh[l], B, 3 * H, w.gh, stream));
+                TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
+            } else {
+                return rc;
+            }
             in = hl;
             in_dim = H;
         }
@@ -109,8 +120,11 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     }
 #undef TRY
     if (h_final) {
-        e = hipMemcpyAsync(h_final, w.h, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
-        if (e != hipSuccess) return (int)e;
+        for (int l = 0; l < L; ++l) {
+            e = hipMemcpyAsync(h_final + (size_t)l * B * H, w.h + ((size_t)cur[l] * L + l) * B * H, (size_t)B * H * 4,
+                               hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return (int)e;
+        }
     }
     return DSSVAE_OK;
 }

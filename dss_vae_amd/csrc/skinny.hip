@@ -181,6 +181,102 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     }
 }
 
+// One GRU cell step for a decode batch, fused: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh and the gate math
+// (decoder/rnn_decoder.py:61-66 from the greedy loop :160-168) in ONE launch instead of three.  A workgroup owns
+// 16 hidden units for 32 batch rows; [x | h] sits in LDS; six of its eight waves each stream one of the six
+// (gate, operand) weight blocks -- 16 rows of W_ih or W_hh over their whole K -- into the MFMA A operand; the
+// partial pre-activations meet in LDS and two waves (one per 16-row tile) apply the cell and write h'.
+// h' goes to a buffer of its own (other workgroups still read h).
+__device__ __forceinline__ float sk_sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+__global__ __launch_bounds__(SK_THREADS) void skinny_gru_kernel(
+    const float* __restrict__ X, int64_t ldx, int In, const float* __restrict__ Hp, int64_t ldh, int H,
+    const float* __restrict__ Wih, int64_t ldi, const float* __restrict__ Whh, int64_t ldhh,
+    const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp] = [x .. 0 | h .. 0], each padded to 16
+    __shared__ __attribute__((aligned(16))) float part[6][2][64][4];
+    const int Inp = (In + 15) & ~15;
+    const int m0 = blockIdx.y * SK_ROWS;
+    const int kp4 = Kp >> 2;
+    for (int idx = threadIdx.x; idx < SK_ROWS * kp4; idx += SK_THREADS) {
+        const int r = idx / kp4, k = (idx - r * kp4) << 2;
+        const int m = m0 + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m < M) {
+            if (k < In) v = *reinterpret_cast<const float4*>(X + (int64_t)m * ldx + k);
+            else if (k >= Inp && k - Inp < H) v = *reinterpret_cast<const float4*>(Hp + (int64_t)m * ldh + (k - Inp));
+        }
+        *reinterpret_cast<float4*>(Xs + r * Kp + k) = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int u0 = blockIdx.x * 16;
+    if (wave < 6) {
+        const int gate = wave >> 1, panel = wave & 1;
+        const int Kw = panel ? H : In, xoff = panel ? Inp : 0;
+        const float* wrow = (panel ? Whh : Wih) + (int64_t)(gate * H + min(u0 + r16, H - 1)) * (panel ? ldhh : ldi) + 4 * kq;
+        const float* xs0 = Xs + r16 * Kp + xoff + 4 * kq;
+        const float* xs1 = xs0 + 16 * Kp;
+        const int nG = (Kw + 15) >> 4;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        f32x4 cur[SK_GC], nxt[SK_GC];
+#pragma unroll
+        for (int i = 0; i < SK_GC; ++i) {
+            const bool ok = i < nG && 16 * i + 4 * kq < Kw;
+            cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        for (int g0 = 0; g0 < nG; g0 += SK_GC) {
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) {
+                const int g = g0 + SK_GC + i;
+                const bool ok = g < nG && 16 * g + 4 * kq < Kw;
+                nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) {
+                if (g0 + i < nG) {
+                    // past Kw both the weight registers and the image's padding are zero
+                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
+                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x0[j], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x1[j], acc1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+        }
+        *reinterpret_cast<f32x4*>(&part[wave][0][lane][0]) = acc0;
+        *reinterpret_cast<f32x4*>(&part[wave][1][lane][0]) = acc1;
+    }
+    __syncthreads();
+    if (wave < 2) {
+        // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16
+        const int m = m0 + 16 * wave + r16;
+        const f32x4 rx = *reinterpret_cast<const f32x4*>(&part[0][wave][lane][0]);
+        const f32x4 rh = *reinterpret_cast<const f32x4*>(&part[1][wave][lane][0]);
+        const f32x4 zx = *reinterpret_cast<const f32x4*>(&part[2][wave][lane][0]);
+        const f32x4 zh = *reinterpret_cast<const f32x4*>(&part[3][wave][lane][0]);
+        const f32x4 nx = *reinterpret_cast<const f32x4*>(&part[4][wave][lane][0]);
+        const f32x4 nh = *reinterpret_cast<const f32x4*>(&part[5][wave][lane][0]);
+        const float* hold = Xs + (16 * wave + r16) * Kp + Inp;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int u = u0 + 4 * kq + c;
+            if (m < M && u < H) {
+                // same association as the unfused path: (x W^T + b_ih) + (h W^T + b_hh)
+                const float r = sk_sigm((rx[c] + bih[u]) + (rh[c] + bhh[u]));
+                const float z = sk_sigm((zx[c] + bih[H + u]) + (zh[c] + bhh[H + u]));
+                const float n = tanhf((nx[c] + bih[2 * H + u]) + r * (nh[c] + bhh[2 * H + u]));
+                Hn[(int64_t)m * ldo + u] = (1.f - z) * n + z * hold[u];
+            }
+        }
+    }
+}
+
 int sk_cus() {
     static int cus = 0;
     if (cus == 0) {
@@ -260,4 +356,25 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
     const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
     return sk_launch<true, 1>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
                            part_max, part_sum, part_arg, (hipStream_t)stream);
+}
+
+extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H,
+                                      const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
+                                      const float* bih, const float* bhh, int M, float* Hnew, int64_t ldo,
+                                      void* stream) {
+    if (!X || !Hprev || !Wih || !Whh || !bih || !bhh || !Hnew || M <= 0 || In <= 0 || H <= 0 || ldx < In || ldh < H ||
+        ldi < In || ldhh < H || ldo < H || Hnew == Hprev)
+        return DSSVAE_EINVAL;
+    if (M > DSSVAE_SKINNY_MAX_ROWS || (In % 4) || (H % 4) || (ldx % 4) || (ldh % 4) || (ldi % 4) || (ldhh % 4) ||
+        !aligned16(X) || !aligned16(Hprev) || !aligned16(Wih) || !aligned16(Whh))
+        return DSSVAE_ETOOBIG;
+    const int Kp = ((In + 15) & ~15) + padded_k(H);
+    const int lds = SK_ROWS * Kp * 4;
+    if (lds + 6 * 2 * 64 * 4 * 4 > SK_LDS_BUDGET) return DSSVAE_ETOOBIG;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(skinny_gru_kernel, dim3((H + 15) / 16, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds,
+                       (hipStream_t)stream, X, ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
 }

@@ -237,6 +237,14 @@ int dssvae_skinny_argmax_splits(int M, int N);
 int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* C, int64_t ldc,
                          void* stream);
+/* One GRU cell step of a decode batch in one launch: h_new = GRUCell(x, h) with gi = x W_ih^T + b_ih,
+ * gh = h W_hh^T + b_hh (decoder/rnn_decoder.py:61-66 in the greedy loop :160-168).  h_new must not alias
+ * h_prev.  DSSVAE_ETOOBIG when the shape is outside the kernel's range (M > DSSVAE_SKINNY_MAX_ROWS, extents
+ * not multiples of 4, [x | h] rows beyond the LDS budget): the caller then uses dssvae_skinny_linear /
+ * dssvae_gemm_f32 + dssvae_gru_cell. */
+int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const float* h_prev, int64_t ldh, int H,
+                           const float* w_ih, int64_t ld_ih, const float* w_hh, int64_t ld_hh,
+                           const float* b_ih, const float* b_hh, int M, float* h_new, int64_t ldo, void* stream);
 int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
                          float* part_sum, int64_t* part_arg, void* stream);

@@ -374,6 +374,28 @@ def test_skinny_linear_and_argmax(M, K1, K2, N):
                                     L.stream()) == -2
 
 
+@pytest.mark.parametrize("M,In,H", [(1, 4, 4), (50, 300, 512), (33, 12, 20), (128, 512, 100), (7, 100, 36)])
+def test_skinny_gru_step(M, In, H):
+    """fused decode cell step (one launch) vs nn.GRUCell in fp64; refused shapes answer ETOOBIG"""
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    x, h = rnd(M, In, seed=1), rnd(M, H, seed=2)
+    wih, whh = rnd(3 * H, In, seed=3, scale=0.3), rnd(3 * H, H, seed=4, scale=0.3)
+    bih, bhh = rnd(3 * H, seed=5), rnd(3 * H, seed=6)
+    cell = torch.nn.GRUCell(In, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(wih), cell.weight_hh.copy_(whh), cell.bias_ih.copy_(bih), cell.bias_hh.copy_(bhh)
+        want = cell(x.double(), h.double())
+    d = [t.to(DEV) for t in (x, h, wih, whh, bih, bhh)]
+    out = torch.full((M, H), float("nan"), device=DEV)
+    L.check(lib.dssvae_skinny_gru_step(L.ptr(d[0]), In, In, L.ptr(d[1]), H, H, L.ptr(d[2]), In, L.ptr(d[3]), H,
+                                       L.ptr(d[4]), L.ptr(d[5]), M, L.ptr(out), H, L.stream()), "skinny_gru_step")
+    close(out, want, rtol=1e-4, atol=1e-5, what="fused cell step")
+    args = [L.ptr(d[0]), In, In, L.ptr(d[1]), H, H, L.ptr(d[2]), In, L.ptr(d[3]), H, L.ptr(d[4]), L.ptr(d[5])]
+    assert lib.dssvae_skinny_gru_step(*args, 129, L.ptr(out), H, L.stream()) == -2
+    assert lib.dssvae_skinny_gru_step(*args, M, L.ptr(d[1]), H, L.stream()) == -1  # h_new must not alias h_prev
+
+
 def test_sumsq_and_adam():
     from dss_vae_amd import ops
     n = 100003
