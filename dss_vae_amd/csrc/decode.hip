@@ -1,7 +1,8 @@
 // Greedy generation loop (decoder/rnn_decoder.py:160-168,193-199) as ONE native call: for max_len steps,
 // embedding rows of the previous tokens -> per layer two small MFMA GEMMs (x W_ih^T + b_ih, h W_hh^T + b_hh)
-// + the fused GRU cell -> output projection fused with a running arg-max over vocabulary splits (no
-// softmax is needed for an arg-max, no [B,V] row is written) -> tokens[t].  The host loop only enqueues
+// + the GRU cell (one fused launch per layer when the shape allows) -> output projection fused with a running
+// arg-max over vocabulary splits (no softmax is needed for an arg-max, no [B,V] row is written) -> tokens[t]
+// and the next step's embedding rows.  The host loop only enqueues
 // kernels on the caller's stream: no allocation, no synchronisation, no device->host traffic (the
 // reference does a topk + .cpu() per step), so the whole decode is also capturable in a HIP graph.
 #include "common.h"
@@ -43,6 +44,35 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     if (i < n) p[i] = v;
 }
 
+// Best of the S vocabulary splits of a step (ties: the smaller split, i.e. the smaller column, as
+// lse_combine_kernel) -> tokens[t], and straight on to the embedding rows of those tokens -> x, the input of
+// step t+1: one wave per sentence, one launch instead of two.
+__global__ void combine_gather_kernel(const float* __restrict__ pm, const int64_t* __restrict__ pa, int M, int S,
+                                      int64_t* __restrict__ tok_out, const float* __restrict__ table, int64_t ldt,
+                                      int E, float* __restrict__ x) {
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const int lane = threadIdx.x & 63;
+    const float* rm = pm + (int64_t)m * S;
+    float mx = -3.0e38f;
+    int best = 0x7fffffff;
+    for (int s = lane; s < S; s += 64) {
+        const float v = rm[s];
+        if (v > mx) { mx = v; best = s; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float m2 = __shfl_xor(mx, o, 64);
+        const int b2 = __shfl_xor(best, o, 64);
+        if (m2 > mx || (m2 == mx && b2 < best)) { mx = m2; best = b2; }
+    }
+    const int64_t tok = pa[(int64_t)m * S + (best == 0x7fffffff ? 0 : best)];  // same in every lane
+    if (lane == 0) tok_out[m] = tok;
+    const float* src = table + tok * ldt;
+    float* dst = x + (int64_t)m * E;
+    for (int e = lane; e < E; e += 64) dst[e] = src[e];
+}
+
 // partial columns: enough for the general kernel's n_split and for the skinny kernel's own split count
 // (at most one 16-column block per workgroup)
 inline int part_cols(int n_split, int V) { return max(n_split, (V + 15) / 16); }
@@ -67,7 +97,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     if (!p || !h0 || !tokens || !workspace || B <= 0 || max_len <= 0 || n_split <= 0) return DSSVAE_EINVAL;
     const int E = p->E, H = p->H, L = p->n_layers, V = p->V;
     if (E <= 0 || H <= 0 || V <= 0 || L <= 0 || L > DSSVAE_DECODE_MAX_LAYERS || !p->embedding || !p->w_out ||
-        p->ld_embedding < E || p->ld_out < H + E || sos_id < 0 || sos_id >= p->n_embeddings)
+        p->ld_embedding < E || p->ld_out < H + E || sos_id < 0 || sos_id >= p->n_embeddings || p->n_embeddings < V)
         return DSSVAE_EINVAL;
     for (int l = 0; l < L; ++l)
         if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return DSSVAE_EINVAL;
@@ -82,11 +112,10 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     int rc;
     int cur[DSSVAE_DECODE_MAX_LAYERS] = {0, 0, 0, 0};  // which half of the ping-pong holds layer l's state
 #define TRY(call) do { rc = (call); if (rc != DSSVAE_OK) return rc; } while (0)
+    TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, w.tok, B, E, nullptr, w.x, E, stream));
     for (int t = 0; t < max_len; ++t) {
-        // the arg-max of step t-1 went straight into tokens[t-1]: it is also this step's input (no per-step
-        // device-to-device copy: the runtime's blit path costs more than the step's kernels)
-        const int64_t* prev = t == 0 ? w.tok : tokens + (size_t)(t - 1) * B;
-        TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, prev, B, E, nullptr, w.x, E, stream));
+        // x holds the embedding rows of the previous tokens: the kernel that picks the tokens of a step also
+        // fetches their rows (no per-step copy or gather launch: at ~4.5 us each they cost as much as a cell)
         const float* in = w.x;
         int in_dim = E;
         for (int l = 0; l < L; ++l) {
@@ -116,7 +145,9 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
                                        w.psum, w.parg, 1, nullptr, 0, stream);
         }
         if (rc != DSSVAE_OK) return rc;
-        TRY(dssvae_lse_combine(w.pmax, w.psum, w.parg, B, S, nullptr, tokens + (size_t)t * B, stream));
+        hipLaunchKernelGGL(combine_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pmax, w.parg, B, S,
+                           tokens + (size_t)t * B, p->embedding, p->ld_embedding, E, w.x);
+        DSSVAE_CHECK_LAUNCH();
     }
 #undef TRY
     if (h_final) {

@@ -14,13 +14,44 @@ namespace {
 constexpr int SK_ROWS = 32;       // activation rows per workgroup (2 MFMA tiles of 16)
 constexpr int SK_THREADS = 512;   // 8 waves
 constexpr int SK_WAVES = SK_THREADS / 64;
-constexpr int SK_GC = 4;          // k-groups (16 k each) per register chunk
+constexpr int SK_GC = 4;          // k-groups (16 k each) per register chunk: gate products (latency-bound chains)
+constexpr int SK_GC_STREAM = 16;  // ... and for the vocabulary stream: 16 KB per wave in flight to cover the fabric latency
 constexpr int SK_LDS_BUDGET = 150 * 1024;
 constexpr float SK_NEG = -3.0e38f;
 
 // row stride of the LDS image: multiple of 16 k plus 4 floats => stride = 4 (mod 8) floats, so the 16 rows
 // read by one 16-lane group of a ds_read_b128 fall into 16 distinct 4-bank slots (conflict-free)
 inline int padded_k(int K) { return ((K + 15) / 16) * 16 + 4; }
+
+// Build the LDS image [rows][Kp] of a workgroup's activation rows: `fetch(r, k)` answers the float4 at row r,
+// columns k..k+3 (zeros for padding).  Eight loads are in flight per thread before the first LDS store: with
+// one load per trip (load -> wait -> store) the fill is ~60 dependent L2 round trips and takes longer than
+// the weight stream it prepares.
+template <int THREADS, class F>
+__device__ __forceinline__ void fill_image(float* Xs, int rows, int Kp, F fetch) {
+    constexpr int U = 8;
+    const int kp4 = Kp >> 2, total = rows * kp4;
+    for (int base = threadIdx.x; base < total; base += THREADS * U) {
+        float4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * THREADS;
+            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total) {
+                const int r = idx / kp4;
+                v[u] = fetch(r, (idx - r * kp4) << 2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = base + u * THREADS;
+            if (idx < total) {
+                const int r = idx / kp4;
+                *reinterpret_cast<float4*>(Xs + r * Kp + ((idx - r * kp4) << 2)) = v[u];
+            }
+        }
+    }
+}
 
 // KS = waves that share one 16-column block, each taking a contiguous range of k (partials summed
 // through LDS).  The arg-max streams hundreds of blocks per workgroup (throughput-bound: KS = 1); the
@@ -31,29 +62,32 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     const float* __restrict__ X1, int64_t ld1, int K1, const float* __restrict__ X2, int64_t ld2, int K2,
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp,
     int blocks_per_wg, float* __restrict__ C, int64_t ldc, int cvec, float* __restrict__ part_max,
-    float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split) {
+    float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split, int m_chunks) {
     extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp]
     __shared__ float red_v[SK_WAVES][SK_ROWS];
     __shared__ int red_i[SK_WAVES][SK_ROWS];
     __shared__ __attribute__((aligned(16))) float part[KS > 1 ? SK_WAVES : 1][2][64][4];
+    constexpr int GC = ARGMAX ? SK_GC_STREAM : SK_GC;
+    // workgroup id -> (column range bx, row chunk by): ids go round-robin over the 8 XCDs, so the row chunks of
+    // one column range get consecutive slots of ONE XCD: they stream the same rows of W at about the same
+    // time and the second read is served by that XCD's L2 instead of crossing the fabric again
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int bx = (seq / m_chunks) * 8 + xcd, by = seq % m_chunks;
+    if (bx >= n_split) return;
     const int K = K1 + K2;
-    const int m0 = blockIdx.y * SK_ROWS;
-    const int kp4 = Kp >> 2;
-    for (int idx = threadIdx.x; idx < SK_ROWS * kp4; idx += SK_THREADS) {
-        const int r = idx / kp4, k = (idx - r * kp4) << 2;
+    const int m0 = by * SK_ROWS;
+    fill_image<SK_THREADS>(Xs, SK_ROWS, Kp, [&](int r, int k) {
         const int m = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M && k < K)
-            v = k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
-                       : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
-        *reinterpret_cast<float4*>(Xs + r * Kp + k) = v;
-    }
+        if (m >= M || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
+        return k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
+                      : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
+    });
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int nG = (K + 15) >> 4;
     const int NB = (N + 15) >> 4;
-    const int b_begin = blockIdx.x * blocks_per_wg, b_end = min(NB, b_begin + blocks_per_wg);
+    const int b_begin = bx * blocks_per_wg, b_end = min(NB, b_begin + blocks_per_wg);
     float best_v[2] = {SK_NEG, SK_NEG};
     int best_i[2] = {0, 0};
     const float* xs0 = Xs + r16 * Kp + 4 * kq;
@@ -71,22 +105,22 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
         const float* wrow = W + (int64_t)n * ldw + 4 * kq;
         f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
         if (active) {
-            f32x4 cur[SK_GC], nxt[SK_GC];
+            f32x4 cur[GC], nxt[GC];
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) {
+            for (int i = 0; i < GC; ++i) {
                 const int g = g_lo + i;
                 const bool ok = g < g_hi && 16 * g + 4 * kq < K;
                 cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            for (int g0 = g_lo; g0 < g_hi; g0 += SK_GC) {
+            for (int g0 = g_lo; g0 < g_hi; g0 += GC) {
 #pragma unroll
-                for (int i = 0; i < SK_GC; ++i) {
-                    const int g = g0 + SK_GC + i;
+                for (int i = 0; i < GC; ++i) {
+                    const int g = g0 + GC + i;
                     const bool ok = g < g_hi && 16 * g + 4 * kq < K;
                     nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
                 }
 #pragma unroll
-                for (int i = 0; i < SK_GC; ++i) {
+                for (int i = 0; i < GC; ++i) {
                     if (g0 + i < g_hi) {
                         const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
                         const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
@@ -98,7 +132,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
                     }
                 }
 #pragma unroll
-                for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+                for (int i = 0; i < GC; ++i) cur[i] = nxt[i];
             }
         }
         if (KS > 1) {
@@ -174,103 +208,113 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
                 const int i2 = red_i[w][threadIdx.x];
                 if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
             }
-            part_max[(int64_t)m * n_split + blockIdx.x] = v;
-            part_sum[(int64_t)m * n_split + blockIdx.x] = 1.f;
-            part_arg[(int64_t)m * n_split + blockIdx.x] = ix;
+            part_max[(int64_t)m * n_split + bx] = v;
+            part_sum[(int64_t)m * n_split + bx] = 1.f;
+            part_arg[(int64_t)m * n_split + bx] = ix;
         }
     }
 }
 
 // One GRU cell step for a decode batch, fused: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh and the gate math
 // (decoder/rnn_decoder.py:61-66 from the greedy loop :160-168) in ONE launch instead of three.  A workgroup owns
-// 16 hidden units for 32 batch rows; [x | h] sits in LDS; six of its eight waves each stream one of the six
-// (gate, operand) weight blocks -- 16 rows of W_ih or W_hh over their whole K -- into the MFMA A operand; the
-// partial pre-activations meet in LDS and two waves (one per 16-row tile) apply the cell and write h'.
+// 16 hidden units for 16 MT batch rows; [x | h] sits in LDS; its twelve waves each stream half the K range of
+// one of the six (gate, operand) weight blocks -- 16 rows of W_ih or W_hh -- into the MFMA A operand (the
+// products are chains of memory round trips: twelve short chains instead of six long ones); the partial
+// pre-activations meet in LDS and one wave per 16-row tile applies the cell and writes h'.
 // h' goes to a buffer of its own (other workgroups still read h).
+constexpr int SKG_WAVES = 12;
+constexpr int SKG_THREADS = SKG_WAVES * 64;
+constexpr int SKG_GC = 12;  // a wave's whole k range (H <= 768) is in flight at once: one memory round trip
+
 __device__ __forceinline__ float sk_sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
-__global__ __launch_bounds__(SK_THREADS) void skinny_gru_kernel(
+template <int MT>
+__global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const float* __restrict__ X, int64_t ldx, int In, const float* __restrict__ Hp, int64_t ldh, int H,
     const float* __restrict__ Wih, int64_t ldi, const float* __restrict__ Whh, int64_t ldhh,
-    const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo) {
-    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp] = [x .. 0 | h .. 0], each padded to 16
-    __shared__ __attribute__((aligned(16))) float part[6][2][64][4];
+    const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo,
+    int n_ub, int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [16 MT][Kp] = [x .. 0 | h .. 0], each padded to 16
+    __shared__ __attribute__((aligned(16))) float part[SKG_WAVES][MT][64][4];
+    constexpr int ROWS = 16 * MT;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // row chunks of one unit block share an XCD (see above)
+    const int bx = (seq / m_chunks) * 8 + xcd, by = seq % m_chunks;
+    if (bx >= n_ub) return;
     const int Inp = (In + 15) & ~15;
-    const int m0 = blockIdx.y * SK_ROWS;
-    const int kp4 = Kp >> 2;
-    for (int idx = threadIdx.x; idx < SK_ROWS * kp4; idx += SK_THREADS) {
-        const int r = idx / kp4, k = (idx - r * kp4) << 2;
-        const int m = m0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m < M) {
-            if (k < In) v = *reinterpret_cast<const float4*>(X + (int64_t)m * ldx + k);
-            else if (k >= Inp && k - Inp < H) v = *reinterpret_cast<const float4*>(Hp + (int64_t)m * ldh + (k - Inp));
-        }
-        *reinterpret_cast<float4*>(Xs + r * Kp + k) = v;
-    }
-    __syncthreads();
+    const int m0 = by * ROWS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
-    const int u0 = blockIdx.x * 16;
-    if (wave < 6) {
-        const int gate = wave >> 1, panel = wave & 1;
-        const int Kw = panel ? H : In, xoff = panel ? Inp : 0;
-        const float* wrow = (panel ? Whh : Wih) + (int64_t)(gate * H + min(u0 + r16, H - 1)) * (panel ? ldhh : ldi) + 4 * kq;
-        const float* xs0 = Xs + r16 * Kp + xoff + 4 * kq;
-        const float* xs1 = xs0 + 16 * Kp;
-        const int nG = (Kw + 15) >> 4;
-        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-        f32x4 cur[SK_GC], nxt[SK_GC];
+    const int u0 = bx * 16;
+    const int prod = wave % 6, khalf = wave / 6;
+    const int gate = prod >> 1, panel = prod & 1;
+    const int Kw = panel ? H : In, xoff = panel ? Inp : 0;
+    const float* wrow = (panel ? Whh : Wih) + (int64_t)(gate * H + min(u0 + r16, H - 1)) * (panel ? ldhh : ldi) + 4 * kq;
+    const int nG = (Kw + 15) >> 4, gper = (nG + 1) >> 1;
+    const int g_lo = khalf * gper, g_hi = min(nG, g_lo + gper);
+    // the first weight chunk is on its way while the workgroup builds the [x | h] image
+    f32x4 cur[SKG_GC], nxt[SKG_GC];
 #pragma unroll
-        for (int i = 0; i < SK_GC; ++i) {
-            const bool ok = i < nG && 16 * i + 4 * kq < Kw;
-            cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        for (int g0 = 0; g0 < nG; g0 += SK_GC) {
+    for (int i = 0; i < SKG_GC; ++i) {
+        const int g = g_lo + i;
+        const bool ok = g < g_hi && 16 * g + 4 * kq < Kw;
+        cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    fill_image<SKG_THREADS>(Xs, ROWS, Kp, [&](int r, int k) {
+        const int m = m0 + r;
+        if (m < M && k < In) return *reinterpret_cast<const float4*>(X + (int64_t)m * ldx + k);
+        if (m < M && k >= Inp && k - Inp < H) return *reinterpret_cast<const float4*>(Hp + (int64_t)m * ldh + (k - Inp));
+        return make_float4(0.f, 0.f, 0.f, 0.f);
+    });
+    __syncthreads();
+    {
+        const float* xs = Xs + r16 * Kp + xoff + 4 * kq;
+        f32x4 acc[MT];
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) {
-                const int g = g0 + SK_GC + i;
-                const bool ok = g < nG && 16 * g + 4 * kq < Kw;
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g0 = g_lo; g0 < g_hi; g0 += SKG_GC) {
+#pragma unroll
+            for (int i = 0; i < SKG_GC; ++i) {
+                const int g = g0 + SKG_GC + i;
+                const bool ok = g < g_hi && 16 * g + 4 * kq < Kw;
                 nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) {
-                if (g0 + i < nG) {
+            for (int i = 0; i < SKG_GC; ++i) {
+                if (g0 + i < g_hi) {
                     // past Kw both the weight registers and the image's padding are zero
-                    const f32x4 x0 = *reinterpret_cast<const f32x4*>(xs0 + 16 * (g0 + i));
-                    const f32x4 x1 = *reinterpret_cast<const f32x4*>(xs1 + 16 * (g0 + i));
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x0[j], acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x1[j], acc1, 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xs + mt * 16 * Kp + 16 * (g0 + i));
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], xv[j], acc[mt], 0, 0, 0);
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < SK_GC; ++i) cur[i] = nxt[i];
+            for (int i = 0; i < SKG_GC; ++i) cur[i] = nxt[i];
         }
-        *reinterpret_cast<f32x4*>(&part[wave][0][lane][0]) = acc0;
-        *reinterpret_cast<f32x4*>(&part[wave][1][lane][0]) = acc1;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&part[wave][mt][lane][0]) = acc[mt];
     }
     __syncthreads();
-    if (wave < 2) {
-        // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16
+    if (wave < MT) {
+        // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16; k halves added low + high
         const int m = m0 + 16 * wave + r16;
-        const f32x4 rx = *reinterpret_cast<const f32x4*>(&part[0][wave][lane][0]);
-        const f32x4 rh = *reinterpret_cast<const f32x4*>(&part[1][wave][lane][0]);
-        const f32x4 zx = *reinterpret_cast<const f32x4*>(&part[2][wave][lane][0]);
-        const f32x4 zh = *reinterpret_cast<const f32x4*>(&part[3][wave][lane][0]);
-        const f32x4 nx = *reinterpret_cast<const f32x4*>(&part[4][wave][lane][0]);
-        const f32x4 nh = *reinterpret_cast<const f32x4*>(&part[5][wave][lane][0]);
+        f32x4 pre[6];
+#pragma unroll
+        for (int q = 0; q < 6; ++q)
+            pre[q] = *reinterpret_cast<const f32x4*>(&part[q][wave][lane][0]) +
+                     *reinterpret_cast<const f32x4*>(&part[6 + q][wave][lane][0]);
         const float* hold = Xs + (16 * wave + r16) * Kp + Inp;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             const int u = u0 + 4 * kq + c;
             if (m < M && u < H) {
                 // same association as the unfused path: (x W^T + b_ih) + (h W^T + b_hh)
-                const float r = sk_sigm((rx[c] + bih[u]) + (rh[c] + bhh[u]));
-                const float z = sk_sigm((zx[c] + bih[H + u]) + (zh[c] + bhh[H + u]));
-                const float n = tanhf((nx[c] + bih[2 * H + u]) + r * (nh[c] + bhh[2 * H + u]));
+                const float r = sk_sigm((pre[0][c] + bih[u]) + (pre[1][c] + bhh[u]));
+                const float z = sk_sigm((pre[2][c] + bih[H + u]) + (pre[3][c] + bhh[H + u]));
+                const float n = tanhf((pre[4][c] + bih[2 * H + u]) + r * (pre[5][c] + bhh[2 * H + u]));
                 Hn[(int64_t)m * ldo + u] = (1.f - z) * n + z * hold[u];
             }
         }
@@ -304,8 +348,9 @@ int sk_launch(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<ARGMAX, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int cvec = C && aligned16(C) && (ldc % 4) == 0;
-    hipLaunchKernelGGL((skinny_kernel<ARGMAX, KS>), dim3(n_wg, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds, s, X1,
-                       ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, Kp, bpw, C, ldc, cvec, pm, ps, pa, n_wg);
+    const int m_chunks = (M + SK_ROWS - 1) / SK_ROWS;
+    hipLaunchKernelGGL((skinny_kernel<ARGMAX, KS>), dim3(((n_wg + 7) / 8) * 8 * m_chunks), dim3(SK_THREADS), lds, s, X1,
+                       ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, Kp, bpw, C, ldc, cvec, pm, ps, pa, n_wg, m_chunks);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -369,12 +414,21 @@ extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const
         !aligned16(X) || !aligned16(Hprev) || !aligned16(Wih) || !aligned16(Whh))
         return DSSVAE_ETOOBIG;
     const int Kp = ((In + 15) & ~15) + padded_k(H);
-    const int lds = SK_ROWS * Kp * 4;
-    if (lds + 6 * 2 * 64 * 4 * 4 > SK_LDS_BUDGET) return DSSVAE_ETOOBIG;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(skinny_gru_kernel, dim3((H + 15) / 16, (M + SK_ROWS - 1) / SK_ROWS), dim3(SK_THREADS), lds,
-                       (hipStream_t)stream, X, ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo);
+    const int n_ub = (H + 15) / 16, grid_x = ((n_ub + 7) / 8) * 8;
+    hipStream_t s = (hipStream_t)stream;
+#define SKG_LAUNCH(MT)                                                                                              \
+    do {                                                                                                            \
+        const int lds = 16 * MT * Kp * 4, m_chunks = (M + 16 * MT - 1) / (16 * MT);                                 \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT>),                             \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
+        hipLaunchKernelGGL(skinny_gru_kernel<MT>, dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X, ldx, In,   \
+                           Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub, m_chunks);         \
+    } while (0)
+    // two 16-row tiles per workgroup when their [x | h] image fits in LDS beside the partials, else one
+    if (32 * Kp * 4 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
+    else if (16 * Kp * 4 + SKG_WAVES * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(1);
+    else return DSSVAE_ETOOBIG;
+#undef SKG_LAUNCH
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -374,7 +374,8 @@ def test_skinny_linear_and_argmax(M, K1, K2, N):
                                     L.stream()) == -2
 
 
-@pytest.mark.parametrize("M,In,H", [(1, 4, 4), (50, 300, 512), (33, 12, 20), (128, 512, 100), (7, 100, 36)])
+@pytest.mark.parametrize("M,In,H", [(1, 4, 4), (50, 300, 512), (33, 12, 20), (128, 512, 100), (7, 100, 36),
+                                    (50, 768, 768), (100, 300, 1000)])
 def test_skinny_gru_step(M, In, H):
     """fused decode cell step (one launch) vs nn.GRUCell in fp64; refused shapes answer ETOOBIG"""
     from dss_vae_amd import lib as L
@@ -394,6 +395,9 @@ def test_skinny_gru_step(M, In, H):
     args = [L.ptr(d[0]), In, In, L.ptr(d[1]), H, H, L.ptr(d[2]), In, L.ptr(d[3]), H, L.ptr(d[4]), L.ptr(d[5])]
     assert lib.dssvae_skinny_gru_step(*args, 129, L.ptr(out), H, L.stream()) == -2
     assert lib.dssvae_skinny_gru_step(*args, M, L.ptr(d[1]), H, L.stream()) == -1  # h_new must not alias h_prev
+    # an [x | h] image beyond the LDS budget even at 16 rows per workgroup (extents only: nothing is launched)
+    assert lib.dssvae_skinny_gru_step(L.ptr(d[0]), 2048, 2048, L.ptr(d[1]), 2048, 2048, L.ptr(d[2]), 2048, L.ptr(d[3]),
+                                      2048, L.ptr(d[4]), L.ptr(d[5]), M, L.ptr(out), 2048, L.stream()) == -2
 
 
 def test_sumsq_and_adam():
