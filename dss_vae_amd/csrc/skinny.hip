@@ -424,8 +424,11 @@ extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const
         hipLaunchKernelGGL(skinny_gru_kernel<MT>, dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X, ldx, In,   \
                            Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub, m_chunks);         \
     } while (0)
-    // two 16-row tiles per workgroup when their [x | h] image fits in LDS beside the partials, else one
-    if (32 * Kp * 4 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
+    // The step is bound by the fp32 MFMA rate of the CUs it occupies, not by the weight stream (a few MB from the
+    // Infinity Cache): one 16-row tile per workgroup spreads it over twice the CUs.  Two tiles per workgroup
+    // (weights fetched once per 32 rows) only when that still fills the chip and the [x | h] image fits in LDS.
+    const bool wide = (int64_t)grid_x * ((M + 31) / 32) >= sk_cus();
+    if (wide && 32 * Kp * 4 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
     else if (16 * Kp * 4 + SKG_WAVES * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(1);
     else return DSSVAE_ETOOBIG;
 #undef SKG_LAUNCH

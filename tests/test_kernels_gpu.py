@@ -375,7 +375,7 @@ def test_skinny_linear_and_argmax(M, K1, K2, N):
 
 
 @pytest.mark.parametrize("M,In,H", [(1, 4, 4), (50, 300, 512), (33, 12, 20), (128, 512, 100), (7, 100, 36),
-                                    (50, 768, 768), (100, 300, 1000)])
+                                    (50, 768, 768), (100, 300, 1000), (128, 64, 1024)])  # last: 32-row workgroups
 def test_skinny_gru_step(M, In, H):
     """fused decode cell step (one launch) vs nn.GRUCell in fp64; refused shapes answer ETOOBIG"""
     from dss_vae_amd import lib as L
