@@ -80,12 +80,13 @@ def training(main_args, model_args, model=None, max_iters=None):
         epoch_begin = time.time()
         train_log_dict = {}
         for global_batch in train_set.batch_iter(batch_size=main_args.batch_size * world, shuffle=True):
+            if len(global_batch) < world:
+                continue  # every rank must take part in the step's collectives: all ranks drop the same tail
             batch_examples = shard_examples(global_batch, rank, world) if world > 1 else global_batch
-            if not batch_examples:
-                continue
             train_iter += 1
             train_nums += len(batch_examples)
-            batch_ret = train_iteration(model, optimizer, batch_examples, train_iter, adv_syn, adv_sem)
+            batch_ret = train_iteration(model, optimizer, batch_examples, train_iter, adv_syn, adv_sem,
+                                        global_batch=len(global_batch))
             batch_loss = batch_ret["Loss"]
             train_log_dict = update_tracker(batch_ret, train_log_dict)
             if train_iter % main_args.log_every == 0:

@@ -153,23 +153,33 @@ class FlatAdam(object):
         self.v.copy_(sd["exp_avg_sq"])
 
 
-def train_iteration(model, optimizer, examples, train_iter, adv_syn=False, adv_sem=False):
+def train_iteration(model, optimizer, examples, train_iter, adv_syn=False, adv_sem=False, global_batch=None):
     """universal_training + the main step (bin/train.py:90-126): with `adv_train`, a discriminator step on
     'dis syn' and one on 'dis sem' (each its own get_loss(is_dis=True) / zero_grad / backward / clip /
-    Adam) precede the main pass."""
+    Adam) precede the main pass.
+
+    Data parallel (optimizer.world > 1): the ranks' gradients are AVERAGED, so each pass scales its loss
+    such that the average equals the single-process gradient at the global batch: the discriminator
+    losses are plain sums over sentences (x world), the main loss is a sum / B_local (x B_local * world /
+    B_global; 1 for equal shards; `global_batch` = number of sentences over all ranks, None = equal shards)."""
+    world = getattr(optimizer, "world", 1)
     for key, tag, on in (("dis syn", "dis_syn", adv_syn), ("dis sem", "dis_sem", adv_sem)):
         if on:
             ret = model.get_loss(examples=examples, train_iter=train_iter, is_dis=True)
             optimizer.zero_grad(tag)
-            ret[key].backward()
+            (ret[key] * float(world) if world > 1 else ret[key]).backward()
             optimizer.step()
-    return train_step(model, optimizer, examples, train_iter)
+    return train_step(model, optimizer, examples, train_iter, global_batch)
 
 
-def train_step(model, optimizer, examples, train_iter):
+def train_step(model, optimizer, examples, train_iter, global_batch=None):
     """one main-pass iteration; returns the loss dict of get_loss."""
     optimizer.zero_grad("main")
     ret = model.get_loss(examples, train_iter)
-    torch.mean(ret["Loss"]).backward()
+    loss = torch.mean(ret["Loss"])
+    world = getattr(optimizer, "world", 1)
+    if world > 1 and global_batch is not None and len(examples) * world != global_batch:
+        loss = loss * (len(examples) * world / float(global_batch))  # unequal shards stay exact
+    loss.backward()
     optimizer.step()
     return ret

@@ -38,18 +38,22 @@ def _setup():
     return model, exs, eps
 
 
-def _run(model, opt, exs, eps, sel):
-    from dss_vae_amd.train import train_step
+def _run(model, opt, exs, eps, sel, adv=False, n_global=None):
+    """adv: the 3-pass adversarial iteration (two discriminator steps + the main step) instead of the main step"""
+    from dss_vae_amd.train import train_iteration, train_step
     losses = []
     for s in range(STEPS):
         model.noise = {"eps_syn": eps[s][0][sel], "eps_sem": eps[s][1][sel]}
-        ret = train_step(model, opt, exs[sel], 6000 + s)
+        if adv:
+            ret = train_iteration(model, opt, exs[sel], 6000 + s, True, True, global_batch=n_global)
+        else:
+            ret = train_step(model, opt, exs[sel], 6000 + s)
         losses.append(float(ret["Loss"]))
     torch.cuda.synchronize()
     return losses
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, n_global=B, adv=False):
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=True)  # a hung rank names its frame instead of stalling the run
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -61,14 +65,16 @@ def _worker(rank, world, port, q):
         model, exs, eps = _setup()
         opt = FlatAdam(model, bucket_mb=0.01)
         assert opt.buckets is not None and len(opt.buckets.buckets) > 3
-        losses = _run(model, opt, exs, eps, slice(rank, None, world))
+        sel = slice(rank, n_global, world)
+        n_local = len(range(*sel.indices(B)))
+        losses = _run(model, opt, exs, eps, sel, adv, n_global)
         assert opt.buckets.sent_early > 0, "second step should have overlapped buckets with backward"
-        lt = torch.tensor(losses, dtype=torch.float64)
+        lt = torch.tensor(losses, dtype=torch.float64) * n_local * world / n_global  # sum / B_local -> share of sum / B
         dist.all_reduce(lt)
         if rank == 0:
             ref, exs, eps = _setup()
             ropt = FlatAdam(ref, data_parallel=False)
-            rl = _run(ref, ropt, exs, eps, slice(None))
+            rl = _run(ref, ropt, exs, eps, slice(0, n_global), adv)
             for a, b in zip((lt / world).tolist(), rl):
                 assert abs(a - b) <= 1e-4 * abs(b), (a, b)
             sd, rsd = model.state_dict(), ref.state_dict()
@@ -84,14 +90,19 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_step_equals_single_process():
+@pytest.mark.parametrize("n_global,adv", [(B, False), (B - 1, True)],
+                         ids=["main_step_equal_shards", "adversarial_iteration_unequal_shards"])
+def test_two_rank_step_equals_single_process(n_global, adv):
+    """second case: 4 + 3 sentences and the 3-pass iteration -- the main loss (sum / B_local) is weighted by the
+    shard size and the discriminator losses (plain sums) by the world size, so that the gradient average is
+    the single-process gradient on all 7 sentences"""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, n_global, adv)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=150) for _ in procs]
