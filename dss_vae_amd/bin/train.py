@@ -13,6 +13,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -56,6 +57,13 @@ def training(main_args, model_args, model=None, max_iters=None):
     model, optimizer, vocab = build_model(main_args=main_args, model_args=model_args, model=model,
                                           seed=getattr(main_args, "seed", None))
     train_set, dev_set = load_data(main_args)
+    if world > 1:
+        # replicas start from rank 0's parameters whatever the ranks' seeds were, and draw different noise
+        dist.broadcast(optimizer.flat, 0)
+        torch.manual_seed(torch.initial_seed() + 7919 * rank)
+        from ..networks.rnn_base import GLOBAL_SEEDS
+        for _ in range(rank):
+            GLOBAL_SEEDS.next()
     model_file, out_dir = dir_ret["model_file"], dir_ret["out_dir"]
     writer = _Scalars(dir_ret["log_dir"], rank == 0)
     print("...... Start Training ......")
@@ -79,7 +87,12 @@ def training(main_args, model_args, model=None, max_iters=None):
         epoch += 1
         epoch_begin = time.time()
         train_log_dict = {}
-        for global_batch in train_set.batch_iter(batch_size=main_args.batch_size * world, shuffle=True):
+        rng = None
+        if world > 1:  # all ranks cut the same global batches: rank 0's draw seeds the epoch's shuffle
+            seed_t = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1))], device="cuda", dtype=torch.int64)
+            dist.broadcast(seed_t, 0)
+            rng = np.random.RandomState(int(seed_t.item()))
+        for global_batch in train_set.batch_iter(batch_size=main_args.batch_size * world, shuffle=True, rng=rng):
             if len(global_batch) < world:
                 continue  # every rank must take part in the step's collectives: all ranks drop the same tail
             batch_examples = shard_examples(global_batch, rank, world) if world > 1 else global_batch
@@ -93,9 +106,16 @@ def training(main_args, model_args, model=None, max_iters=None):
                 ops.check_persistent_errors()
                 train_loss += batch_loss.detach().sum().item() * main_args.log_every  # sampled: no per-step sync
                 print("\r[Iter %d] Train loss=%.5f" % (train_iter, train_loss / train_nums), file=sys.stdout, end=" ")
-                for key, val in train_log_dict.items():
-                    if isinstance(val, torch.Tensor):
-                        writer.add_scalar("{}/Train/{}".format(task_type, key), torch.mean(val).item(), train_iter)
+                keys = sorted(k for k, v in train_log_dict.items() if isinstance(v, torch.Tensor))
+                if keys:
+                    # one device->host copy for all terms; under data parallel one tiny all-reduce first, so
+                    # the logged terms are those of the global batch (same keys on all ranks: same model)
+                    vals = torch.stack([torch.mean(train_log_dict[k].detach().float()) for k in keys]).double()
+                    if world > 1:
+                        dist.all_reduce(vals)
+                        vals /= world
+                    for key, val in zip(keys, vals.tolist()):
+                        writer.add_scalar("{}/Train/{}".format(task_type, key), val, train_iter)
                 writer.add_scalar("Optimize/lr", optimizer.param_groups[0]["lr"], train_iter)
                 writer.add_scalar("Optimize/trial", num_trial, train_iter)
                 writer.add_scalar("Optimize/patience", patience, train_iter)
@@ -122,6 +142,13 @@ def training(main_args, model_args, model=None, max_iters=None):
                                      dtype=torch.float64)
                     dist.broadcast(t, 0)
                     optimizer.param_groups[0]["lr"], num_trial, patience = float(t[0]), int(t[1]), int(t[2])
+                    # ... including what it restored from the checkpoint (Adam moments and step counts on a
+                    # decay): replicas stay bit-identical
+                    for buf in (optimizer.flat, optimizer.m, optimizer.v):
+                        dist.broadcast(buf, 0)
+                    st = torch.tensor(optimizer.steps, device="cuda", dtype=torch.int64)
+                    dist.broadcast(st, 0)
+                    optimizer.steps = [int(x) for x in st.tolist()]
                 model.train()
             if max_iters is not None and train_iter - main_args.start_iter >= max_iters:
                 return {"model": model, "optimizer": optimizer, "train_iter": train_iter, "history": history_scores,

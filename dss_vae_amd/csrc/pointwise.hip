@@ -146,7 +146,12 @@ __global__ void gru_step_bwd_kernel(const float* __restrict__ gates, int64_t g_r
     dhz[i] = g * z;
 }
 
-__global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+// Sum of squares in a FIXED order (block partials -> one block adds them up): data-parallel replicas must
+// compute bit-identical clip coefficients from bit-identical averaged gradients, which float atomics in
+// arrival order do not give.
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n,
+                                                    float* __restrict__ partials) {
+    __shared__ float red[4];
     float acc = 0.f;
     const int64_t n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -156,7 +161,20 @@ __global__ void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __re
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(out, acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restrict__ partials, int n_partials,
+                                                          float* __restrict__ out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_partials; i += 256) acc += partials[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] += (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -289,9 +307,12 @@ extern "C" int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_strid
     return DSSVAE_OK;
 }
 
-extern "C" int dssvae_sumsq(const float* g, int64_t n, float* sumsq_out, void* stream) {
-    if (!g || !sumsq_out || n <= 0 || !aligned16(g)) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, g, n, sumsq_out);
+extern "C" int dssvae_sumsq(const float* g, int64_t n, float* partials, float* sumsq_out, void* stream) {
+    if (!g || !partials || !sumsq_out || n <= 0 || !aligned16(g)) return DSSVAE_EINVAL;
+    const unsigned nb = grid_for(n / 4 + 1, 256, DSSVAE_SUMSQ_PARTIALS);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, g, n, partials);
+    DSSVAE_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, partials, (int)nb, sumsq_out);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -35,6 +35,7 @@ class GruBwdInst(C.Structure):
 
 
 GEMM_MAX_GROUP = 8
+SUMSQ_PARTIALS = 2048
 
 
 class GemmProblem(C.Structure):
@@ -87,7 +88,7 @@ _SIGNATURES = {
     "dssvae_skinny_argmax": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _P, _P, _P], _I),
     "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
     "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),
-    "dssvae_sumsq": ([_P, _L, _P, _P], _I),
+    "dssvae_sumsq": ([_P, _L, _P, _P, _P], _I),
     "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)

@@ -984,8 +984,16 @@ def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
 # ----------------------------------------------------------------------------------------------
 # flat-buffer optimiser pieces
 # ----------------------------------------------------------------------------------------------
+_SUMSQ_WS = {}
+
+
 def sumsq(flat, out):
-    L.check(L.load().dssvae_sumsq(L.ptr(flat), flat.numel(), L.ptr(out), L.stream()), "dssvae_sumsq")
+    """out[0] += sum(flat^2), in a fixed order (bit-identical on every data-parallel replica)"""
+    L.require_cuda(flat, out)
+    ws = _SUMSQ_WS.get(flat.device)
+    if ws is None:
+        ws = _SUMSQ_WS[flat.device] = torch.empty(L.SUMSQ_PARTIALS, device=flat.device)
+    L.check(L.load().dssvae_sumsq(L.ptr(flat), flat.numel(), L.ptr(ws), L.ptr(out), L.stream()), "dssvae_sumsq")
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm):

@@ -45,11 +45,13 @@ class Dataset(object):
     def from_list(raw_list):
         return Dataset([PlainExample.parse_raw(line) for line in raw_list])
 
-    def batch_iter(self, batch_size, shuffle=False):
-        """shuffle, slice, sort each batch by -len(src) (packing needs descending lengths)."""
+    def batch_iter(self, batch_size, shuffle=False, rng=None):
+        """shuffle, slice, sort each batch by -len(src) (packing needs descending lengths).
+        rng: a numpy RandomState for the shuffle (data parallel: the same on every rank); default: the
+        global numpy state, as the reference."""
         order = np.arange(len(self.examples))
         if shuffle:
-            np.random.shuffle(order)
+            (rng or np.random).shuffle(order)
         for lo in range(0, len(order), batch_size):
             batch = [self.examples[i] for i in order[lo:lo + batch_size]]
             batch.sort(key=lambda e: -len(e))

@@ -276,10 +276,12 @@ int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, in
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers (bin/train.py:124-126, utils/model_utils.py:195):
- * sumsq_out[0] += sum(g^2);  Adam step with bias correction and the clip coefficient
+ * sumsq_out[0] += sum(g^2), added up in a fixed order (block partials in `partials`, then one block): the same
+ * bits on every data-parallel replica;  Adam step with bias correction and the clip coefficient
  * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) read on device (no host sync).
  * ------------------------------------------------------------------------------------------- */
-int dssvae_sumsq(const float* g, int64_t n, float* sumsq_out, void* stream);
+#define DSSVAE_SUMSQ_PARTIALS 2048 /* floats of caller-owned scratch for dssvae_sumsq */
+int dssvae_sumsq(const float* g, int64_t n, float* partials, float* sumsq_out, void* stream);
 int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, const float* sumsq, float max_norm,
                      const float* grad_scale_mask, void* stream);

@@ -58,6 +58,72 @@ def test_training_driver_end_to_end(tmp_path):
     assert os.path.exists(os.path.join(base, "base_config.yaml")) and os.path.exists(os.path.join(base, "model_config.yaml"))
 
 
+def _dp_driver_worker(rank, world, port, root, q):
+    import faulthandler
+    import numpy as np
+    import torch.distributed as dist
+    faulthandler.dump_traceback_later(150, exit=True)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dss_vae_amd.bin.train import training
+        np.random.seed(100 + rank)        # ranks disagree on purpose: the driver must not depend on it
+        torch.manual_seed(200 + rank)
+        main_args = Namespace(train_file=os.path.join(root, "train.bin"), dev_file=os.path.join(root, "dev.bin"),
+                              vocab=os.path.join(root, "vocab.bin"), eval_lists=None, logdir=os.path.join(root, "logs"),
+                              model_dir=os.path.join(root, "models"), exp_name="dp", task_type="SyntaxVAE2",
+                              start_iter=0, batch_size=4, log_every=2, dev_every=3, lr=0.0005, lr_decay=0.8,
+                              patience=1, clip_grad=5.0, reset_optimizer=False, mode="train", seed=None)
+        model_args = make_args(warm_up=0, eval_bs=5, dev_item="ELBO", adv_train=True, **TINY)
+        out = training(main_args, model_args, max_iters=7)  # 21 sentences / (4 x 2): tail batch of 5 = 3 + 2
+        flat = out["optimizer"].flat.detach().double().cpu()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        assert torch.equal(both[0], both[1]), "replicas diverged: %g" % (both[0] - both[1]).abs().max().item()
+        assert out["train_iter"] == 7 and torch.isfinite(flat).all()
+        if rank == 0:
+            assert os.path.exists(out["model_file"])
+            tags = {json.loads(line)["tag"] for line in open(os.path.join(out["log_dir"], "scalars.jsonl"))}
+            assert "SyntaxVAE2/Train/Loss" in tags and "SyntaxVAE2/Valid/ELBO" in tags
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "FAIL %r" % (e,)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_training_driver_two_ranks(tmp_path):
+    """the driver under data parallel (two ranks on the one GPU, gloo): differently seeded ranks end with
+    bit-identical replicas after 7 adversarial iterations incl. an unequal tail batch, dev evaluation and
+    rank 0's checkpoint / schedule broadcast"""
+    import socket
+    import torch.multiprocessing as mp
+    from dss_vae_amd.structs import Dataset
+    n_src, n_tgt = 120, 30
+    product_vocab(n_src, n_tgt).save(str(tmp_path / "vocab.bin"))
+    Dataset(product_examples(make_examples(21, n_src, n_tgt, src_len=9, tree_len=27, fixed=False, seed=1))).save(
+        str(tmp_path / "train.bin"))
+    Dataset(product_examples(make_examples(6, n_src, n_tgt, src_len=9, tree_len=27, fixed=False, seed=2))).save(
+        str(tmp_path / "dev.bin"))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_driver_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=200) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
 @pytest.mark.parametrize("model", ["SyntaxVAE2", "DisentangleVAE"])
 def test_three_pass_adversarial_iteration_matches_oracle(model):
     """dis-syn step, dis-sem step, main step, twice; torch.optim.Adam skips parameters without a gradient
