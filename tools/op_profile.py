@@ -26,10 +26,15 @@ def main():
     for i in range(3):
         train_iteration(model, opt, batch, 6001 + i)
     torch.cuda.synchronize()
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False) as prof:
+    shapes = "--shapes" in sys.argv  # per input shape, by device time: which tensors the torch glue ops touch
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=shapes) as prof:
         train_iteration(model, opt, batch, 6010)
         torch.cuda.synchronize()
-    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+    if shapes:
+        print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60,
+                                                                 max_name_column_width=40, max_shapes_column_width=70))
+    else:
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
 
 
 if __name__ == "__main__":
