@@ -74,7 +74,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--shapes", action="store_true", help="development aid: per-shape kernel table on stderr")
-    ap.add_argument("--cpu-batch", type=int, default=32)
+    ap.add_argument("--cpu-batch", type=int, default=256, help="the GPU workload's batch: ~15 s of host work in all")
     ap.add_argument("--cpu-steps", type=int, default=3)
     return ap.parse_args()
 
