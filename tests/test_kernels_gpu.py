@@ -313,7 +313,13 @@ def test_oversized_gru_takes_the_stepwise_path():
     close(hl, hT, rtol=1e-4, atol=1e-4, what="hl")
 
 
-@pytest.mark.parametrize("B,E,H,V,layers,T", [(5, 12, 20, 97, 1, 6), (50, 300, 600, 3001, 2, 9)])
+@pytest.mark.parametrize("B,E,H,V,layers,T", [
+    (5, 12, 20, 97, 1, 6), (50, 300, 600, 3001, 2, 9),
+    (7, 10, 18, 53, 2, 5),         # extents not multiples of 4: every step product through the tiled GEMM
+    (50, 300, 1024, 1000, 2, 4),   # fused cell step with 16-row workgroups (the 32-row image is beyond LDS)
+    (200, 64, 128, 500, 1, 4),     # decode batch beyond the skinny kernels' 128 rows
+    (20, 64, 2048, 300, 1, 3),     # [x | h] image beyond LDS altogether
+])
 def test_native_greedy_decode_loop(B, E, H, V, layers, T):
     """dssvae_greedy_decode (whole loop, one call) vs an explicit fp64 loop of the reference's step"""
     from dss_vae_amd import ops

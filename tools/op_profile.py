@@ -30,7 +30,11 @@ def main():
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=shapes) as prof:
         train_iteration(model, opt, batch, 6010)
         torch.cuda.synchronize()
-    if shapes:
+    if "--counts" in sys.argv:  # which aten ops are launched most often (the tiny-kernel tail of the step)
+        evs = sorted(prof.key_averages(), key=lambda e: -e.count)
+        for e in evs[:45]:
+            print("%-50s x%-5d self cuda %9.1f us" % (e.key[:50], e.count, e.self_device_time_total))
+    elif shapes:
         print(prof.key_averages(group_by_input_shape=True).table(sort_by="self_cuda_time_total", row_limit=60,
                                                                  max_name_column_width=40, max_shapes_column_width=70))
     else:
