@@ -57,6 +57,12 @@ class BaseVAE(nn.Module):
         self.step_kl_weight = args.init_step_kl_weight
         self.noise = {}
 
+    def score(self, **kwargs):  # base_vae.py:23-24
+        raise NotImplementedError
+
+    def batch_beam_decode(self, **kwargs):  # a no-op in the reference (base_vae.py:101-102): the VAEs decode greedily
+        pass
+
     def base_information(self):
         a = self.args
         return "layers:{}\ntypes:{}\nembed:{}\nhidden:{}\nlatent:{}\nkl_factor:{}\nunk_rate:{}\nx0:{}\n".format(

@@ -90,6 +90,40 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
             d[n] = -r.sum()
         return d, res[:ne]
 
+    # ---- the reference's helper surface (enhance_syntax_vae.py:338-403); see SyntaxVAE for the why
+    def _dis_loss(self, syn_hid, sem_hid, syn_tgt, sem_tgt, norm_by_word=False):
+        if norm_by_word:
+            a = self.args
+            return {"sem_to_syn": self.sem_to_syn.forward(sem_hid, syn_tgt, div_by_word=True) if a.sem_to_syn > 0.0 else 0.0,
+                    "syn_to_sem": self.syn_to_sem.forward(hidden=syn_hid, tgt_var=sem_tgt) if a.syn_to_sem > 0.0 else 0.0,
+                    "sem_to_sent": self.sem_to_sent.forward(sem_hid, sem_tgt, div_by_word=True) if a.sem_to_sent > 0.0 else 0.0,
+                    "syn_to_sent": self.syn_to_sent.forward(syn_hid, sem_tgt, div_by_word=True) if a.syn_to_sent > 0.0 else 0.0}
+        return self._dis_terms(syn_hid, sem_hid, syn_tgt, sem_tgt)[0]
+
+    def get_dis_loss(self, syn_hid, sem_hid, syn_tgt, sem_tgt, norm_by_word=False):
+        for n in self.ADVERSARIES:
+            getattr(self, n).reload()
+        d = self._dis_loss(syn_hid.detach(), sem_hid.detach(), syn_tgt, sem_tgt, norm_by_word)
+        if self.args.infer_weight > 0.0:
+            return d["syn_to_sem"] + d["syn_to_sent"], d["sem_to_syn"] + d["sem_to_sent"]
+        return d["syn_to_sem"], d["sem_to_syn"]
+
+    def get_adv_loss(self, syn_hid, sem_hid, syn_tgt, sem_tgt, norm_by_word=False):
+        a = self.args
+        if self.training:
+            for n in self.ADVERSARIES:
+                getattr(self, n).detach()
+        d = self._dis_loss(syn_hid, sem_hid, syn_tgt, sem_tgt, norm_by_word)
+        if a.infer_weight > 0.0:
+            return (a.syn_to_sem * d["syn_to_sem"] + a.infer_weight * a.syn_to_sent * d["syn_to_sent"],
+                    a.sem_to_syn * d["sem_to_syn"] + a.infer_weight * a.sem_to_sent * d["sem_to_sent"])
+        return a.syn_to_sem * d["syn_to_sem"], a.sem_to_syn * d["sem_to_syn"]
+
+    def get_mul_loss(self, syntax_hidden, semantic_hidden, syn_tgt, sem_tgt, norm_by_word=False):
+        syn_loss = self.mul_syn.forward(hidden=syntax_hidden, tgt_var=syn_tgt, div_by_word=norm_by_word)
+        sem_loss = self.mul_sem.forward(hidden=semantic_hidden, tgt_var=sem_tgt)
+        return self.args.mul_syn * syn_loss, self.args.mul_sem * sem_loss
+
     def forward(self, examples, is_dis=False, norm_by_word=False):
         batch, ret = self._front(examples)
         tgt_var, syn_var = batch.tgt_var, batch.syn_var

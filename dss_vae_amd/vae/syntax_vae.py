@@ -251,6 +251,30 @@ class SyntaxVAE(TwoEncoderVAE):
                     a.adv_sem * d["adv_sem_sup"] + a.infer_weight * a.inf_syn * d["adv_syn_inf"])
         return a.adv_syn * d["adv_syn_sup"], a.adv_sem * d["adv_sem_sup"]
 
+    # ---- the reference's helper surface (syntax_vae.py:321-380): same names, arguments and return forms; forward()
+    # below does not go through them (it batches the heads of a pass into shared launches), they are for callers
+    # that want one group of terms
+    def _dis_loss(self, syntax_hidden, semantic_hidden, syn_tgt, sem_tgt):
+        return self._dis_terms(syntax_hidden, semantic_hidden, syn_tgt, sem_tgt)[0]
+
+    def get_dis_loss(self, syntax_hidden, semantic_hidden, syn_tgt, sem_tgt):
+        d = self._dis_loss(syntax_hidden.detach(), semantic_hidden.detach(), syn_tgt, sem_tgt)
+        if self.args.infer_weight > 0.0:
+            return d["adv_syn_sup"] + d["adv_sem_inf"], d["adv_sem_sup"] + d["adv_syn_inf"]
+        return d["adv_syn_sup"], d["adv_sem_sup"]
+
+    def get_adv_loss(self, syntax_hidden, semantic_hidden, syn_tgt, sem_tgt):
+        d, _ = self._dis_terms(syntax_hidden, semantic_hidden, syn_tgt, sem_tgt, no_grad=self.training)
+        return self._adv_weights(d)
+
+    def get_mul_loss(self, syntax_hidden, semantic_hidden, syn_tgt, sem_tgt):
+        syn_loss = self._head_loss(self.sup_syn.forward(hidden=syntax_hidden, tgt_var=syn_tgt))
+        sem_loss = self.sup_sem.forward(hidden=semantic_hidden, tgt_var=sem_tgt)
+        return self.args.mul_syn * syn_loss, self.args.mul_sem * sem_loss
+
+    def extract_variable(self, examples):  # a stub in the reference too (syntax_vae.py:463-464)
+        pass
+
     def forward(self, examples, is_dis=False):
         batch, ret = self._front(examples)
         tgt_var, syn_var = batch.tgt_var, batch.syn_var

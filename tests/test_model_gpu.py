@@ -77,6 +77,32 @@ def test_golden_eval_losses_and_greedy_decodes(case):
             assert [r[0][0] for r in pm.eval_adv(exs, ex2)["res"]] == g["transfer_words"]
 
 
+@pytest.mark.parametrize("case", [c for c in CASES if "Vanilla" not in c])
+def test_reference_helper_surface_matches_loss_dict(case):
+    """get_mul_loss / get_adv_loss / get_dis_loss / _dis_loss (syntax_vae.py:321-380, enhance_syntax_vae.py:338-403):
+    same names and return forms as the reference; their values are the pieces of the golden-pinned loss dict"""
+    g = load_golden(case)
+    _, pm = pair(g, train=False)
+    exs = product_examples(examples(g))
+    step = 10
+    with torch.no_grad():
+        want = pm.get_loss(exs, step)
+        dis = pm.get_loss(exs, step, is_dis=True)
+        batch, ret = pm._front(exs)
+        syn_h, sem_h, B = ret["syn_hidden"], ret["sem_hidden"], len(batch)
+        mul_syn, mul_sem = pm.get_mul_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
+        adv_syn, adv_sem = pm.get_adv_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
+        dis_syn, dis_sem = pm.get_dis_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
+        d = pm._dis_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
+    assert rel_err((mul_syn + mul_sem) / B, want["MUL Loss"]) < 1e-4
+    assert rel_err((adv_syn + adv_sem) / B, want["ADV Loss"]) < 1e-4
+    assert rel_err(dis_syn, dis["dis syn"]) < 1e-4 and rel_err(dis_sem, dis["dis sem"]) < 1e-4
+    assert len(d) in (2, 4) and all(isinstance(k, str) for k in d)
+    assert pm.batch_beam_decode() is None and pm.extract_variable(exs) is None if hasattr(pm, "extract_variable") else True
+    with pytest.raises(NotImplementedError):
+        pm.score()
+
+
 @pytest.mark.parametrize("case", CASES)
 def test_golden_train_losses_grads_and_discriminator(case):
     g = load_golden(case)
