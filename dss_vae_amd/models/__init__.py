@@ -18,3 +18,11 @@ def init_create_model(model: str, **kwargs):
         raise ValueError("Invalid model class '{}' provided. Only {} are supported now.".format(
             model, list(MODEL_CLS.keys())))
     return MODEL_CLS[model](**kwargs)
+
+
+def load_static_model(model: str, model_path: str):
+    """models/__init__.py:36-43"""
+    if model not in MODEL_CLS:
+        raise ValueError("Invalid model class '{}' provided. Only {} are supported now.".format(
+            model, list(MODEL_CLS.keys())))
+    return MODEL_CLS[model].load(model_path)

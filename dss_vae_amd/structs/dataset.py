@@ -19,6 +19,14 @@ class PlainExample(object):
         tgt = items[1].split(token_split) if len(items) > 1 else None
         return PlainExample(src=items[0].split(token_split), tgt=tgt)
 
+    @staticmethod
+    def parse_for_control(raw_line, field_split="\t", token_split=" "):
+        """`sentence \t reference` line of a controlled-generation file -> two source-only examples
+        (structs/dataset.py:114-119)"""
+        items = raw_line.strip().split(field_split)
+        return (PlainExample(src=items[0].split(token_split), tgt=None),
+                PlainExample(src=items[1].split(token_split), tgt=None))
+
     def __len__(self):
         return len(self.src)
 
@@ -40,6 +48,16 @@ class Dataset(object):
         """a pickled LIST of examples, as structs/generate_dataset.py:146-157 writes it"""
         from .io import dump_bin
         dump_bin(list(self.examples), file_path)
+
+    @staticmethod
+    def from_raw_file(file_path, e_type="Plain"):
+        """one `src [\t tgt]` line per example (structs/dataset.py:46-57).  The treebank example types ("PTB",
+        "SyntaxGEN") parse bracketed trees with nltk and belong to preprocessing, which is out of scope."""
+        if e_type not in ("Plain", "NAG", "SyntaxVAE"):
+            raise NotImplementedError("example type %r needs the treebank preprocessing (nltk); only the plain "
+                                      "`src \\t tgt` line format is read here" % (e_type,))
+        with open(file_path, "r") as f:
+            return Dataset([PlainExample.parse_raw(line) for line in f])
 
     @staticmethod
     def from_list(raw_list):

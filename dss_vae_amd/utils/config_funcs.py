@@ -21,3 +21,11 @@ def dict_to_args(d):
 
 def args_to_dict(args):
     return dict(vars(args))
+
+
+def args_to_yaml(yaml_out_file, args):
+    dict_to_yaml(yaml_out_file=yaml_out_file, dicts=args_to_dict(args))
+
+
+def yaml_to_args(yaml_in_file):
+    return dict_to_args(yaml_to_dict(yaml_in_file=yaml_in_file))

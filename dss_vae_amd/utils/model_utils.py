@@ -2,6 +2,7 @@
 model directory layout, build_model (U(-0.08,0.08) re-init, Adam betas (0.9,0.995)), checkpoint +
 patience / lr-decay schedule.  Differences from the reference, all host-side: no interactive prompt
 when a log directory exists; the optimiser is the flat-buffer FlatAdam (same update rule)."""
+import math
 import os
 import sys
 
@@ -79,3 +80,55 @@ def get_lr_schedule(is_better, model, optimizer, main_args, patience, num_trial,
     if optimizer.param_groups[0]["lr"] <= 1e-6:
         print("early stop!", file=sys.stdout)
     return model, optimizer, num_trial, patience
+
+
+# ---- the rest of utils/model_utils.py's surface -------------------------------------------------
+def lr_transformer(args, i, lr0=0.1):
+    """utils/model_utils.py:33-34"""
+    return lr0 * 10 / math.sqrt(args.d_model) * min(1 / math.sqrt(i), i / (args.warmup * math.sqrt(args.warmup)))
+
+
+def get_lr_anneal(args, train_iter):
+    """utils/model_utils.py:37-39"""
+    lr_end = 1e-5
+    return max(0, (args.lr - lr_end) * (args.anneal_steps - train_iter) / args.anneal_steps) + lr_end
+
+
+def update_lr(args, opt, train_iter):
+    """utils/model_utils.py:42-49.  The reference calls its two schedule functions without `args` (a TypeError
+    for every schedule but "fixed"); here they get it."""
+    if args.lr_schedule == "fixed":
+        opt.param_groups[0]["lr"] = args.lr
+    elif args.lr_schedule == "anneal":
+        opt.param_groups[0]["lr"] = get_lr_anneal(args, train_iter + 1)
+    elif args.lr_schedule == "transformer":
+        opt.param_groups[0]["lr"] = lr_transformer(args, train_iter + 1)
+    return opt
+
+
+def get_eval_info(main_args, model_args, mode="Train"):
+    """utils/model_utils.py:100-110: <model_dir>/<model>[.<exp>]/<mode>, created"""
+    parts = [model_args.model_select] + ([main_args.exp_name] if main_args.exp_name is not None else [])
+    model_dir = os.path.join(main_args.model_dir, ".".join(parts), mode)
+    os.makedirs(model_dir, exist_ok=True)
+    return model_dir
+
+
+def load_configs(exp_dir):
+    """utils/model_utils.py:199-204: the two yaml files get_model_info left beside a checkpoint"""
+    from .config_funcs import dict_to_args, yaml_to_dict
+    return (dict_to_args(yaml_to_dict(os.path.join(exp_dir, "base_config.yaml"))["base_configs"]),
+            dict_to_args(yaml_to_dict(os.path.join(exp_dir, "model_config.yaml"))["model_configs"]))
+
+
+def load_model(main_args, model_args, check_dir=True, use_cuda=None):
+    """utils/model_utils.py:213-221: the checkpoint of an experiment -> model (on the MI355X unless use_cuda
+    is False)"""
+    from ..models import load_static_model
+    use_cuda = getattr(model_args, "cuda", True) if use_cuda is None else use_cuda
+    model_file = get_model_info(main_args=main_args, model_args=model_args, check_dir=check_dir)["model_file"]
+    print("Load From:\t{}".format(model_file))
+    model = load_static_model(model=model_args.model_select, model_path=model_file)
+    if use_cuda:
+        model.cuda()
+    return model

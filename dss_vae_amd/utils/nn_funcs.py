@@ -52,6 +52,13 @@ def id2word(sents, vocab):
     return robust_id2word(sents, vocab)
 
 
+def padding_input(sents, pad_token, max_len=-1):
+    """right-pad token lists to a common length (utils/nn_funcs.py:122-129)"""
+    if max_len == -1:
+        max_len = max(len(s) for s in sents)
+    return [list(s) + [pad_token] * (max_len - len(s)) for s in sents]
+
+
 def to_input_variable(sequences, vocab, max_len=-1, cuda=True, training=True, append_boundary_sym=False,
                       batch_first=False, **_):
     """list of token lists -> padded int64 ids on the device ([B,L] if batch_first else [L,B])."""

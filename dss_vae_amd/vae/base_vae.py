@@ -145,6 +145,17 @@ class BaseVAE(nn.Module):
         _, kl = ops.reparam_kl(mean, logv, None)
         return kl, self.get_kl_weight(step)
 
+    @classmethod
+    def load(cls, path, map_location="cpu"):
+        """model.bin ({'args','vocab','state_dict'}, written here or by the reference's save) -> model on the
+        host; call .cuda() to run.  (models/__init__.py:36-43 calls MODEL_CLS[name].load(path); the
+        reference's VAE classes never defined it.)  Nothing in the file is executed: structs/io.py."""
+        from ..structs.io import load_model_bin
+        ck = load_model_bin(path, map_location=map_location)
+        model = cls(args=ck["args"], vocab=ck["vocab"])
+        model.load_state_dict(ck["state_dict"], strict=True)
+        return model
+
     def save(self, path):
         d = os.path.dirname(path)
         if d and not os.path.exists(d):

@@ -272,6 +272,9 @@ class SyntaxVAE(TwoEncoderVAE):
         sem_loss = self.sup_sem.forward(hidden=semantic_hidden, tgt_var=sem_tgt)
         return self.args.mul_syn * syn_loss, self.args.mul_sem * sem_loss
 
+    def get_gpu(self):  # syntax_vae.py:187-194 moves every sub-module to cuda:0
+        return self.cuda()
+
     def extract_variable(self, examples):  # a stub in the reference too (syntax_vae.py:463-464)
         pass
 

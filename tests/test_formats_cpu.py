@@ -119,3 +119,53 @@ def test_update_tracker_concatenates_batch_means():
     t = update_tracker({"Loss": torch.tensor([1.0, 3.0]), "KL Weight": 0.5}, {})
     t = update_tracker({"Loss": torch.tensor(4.0), "KL Weight": 0.25}, t)
     assert torch.equal(t["Loss"], torch.tensor([2.0, 4.0])) and t["KL Weight"] == 0.75
+
+
+def test_raw_file_control_lines_padding_and_bow_helper(tmp_path):
+    """host-side helpers with the reference's names (structs/dataset.py:46-57,114-119, utils/nn_funcs.py:122-129,
+    utils/loss_funcs.py:117-129); bag_of_word_loss against the reference's own expand + NLLLoss formulation"""
+    import torch
+    from dss_vae_amd.structs import Dataset, PlainExample
+    from dss_vae_amd.utils.loss_funcs import bag_of_word_loss
+    from dss_vae_amd.utils.nn_funcs import padding_input
+    f = tmp_path / "raw.txt"
+    f.write_text("a b c\t( S x )\nd e\n")
+    ds = Dataset.from_raw_file(str(f))
+    assert [e.src for e in ds] == [["a", "b", "c"], ["d", "e"]] and ds.examples[0].tgt == ["(", "S", "x", ")"]
+    assert ds.examples[1].tgt is None
+    with pytest.raises(NotImplementedError):
+        Dataset.from_raw_file(str(f), e_type="PTB")
+    x, y = PlainExample.parse_for_control("a b\tc d e\n")
+    assert x.src == ["a", "b"] and y.src == ["c", "d", "e"] and x.tgt is None
+    assert padding_input([["a"], ["b", "c"]], "<pad>") == [["a", "<pad>"], ["b", "c"]]
+    assert padding_input([["a"]], 0, max_len=3) == [["a", 0, 0]]
+    g = torch.Generator().manual_seed(0)
+    logp = torch.log_softmax(torch.randn(3, 1, 11, generator=g), -1)
+    tgt = torch.tensor([[1, 4, 2, 0], [5, 0, 0, 0], [7, 8, 9, 10]])
+    for red in ("sum", "mean"):
+        crit = torch.nn.NLLLoss(ignore_index=0, reduction=red)
+        want = crit(logp.squeeze(1).unsqueeze(1).expand(3, 4, 11).contiguous().view(-1, 11), tgt.view(-1))
+        assert torch.allclose(bag_of_word_loss(logp, tgt, crit), want, rtol=1e-6, atol=1e-6)
+
+
+def test_lr_helpers_and_yaml_args(tmp_path):
+    """utils/model_utils.py:33-49 (with the `args` the reference forgets to pass), utils/config_funcs.py:26-33"""
+    import math
+    from argparse import Namespace
+    from dss_vae_amd.utils.config_funcs import args_to_yaml, yaml_to_dict
+    from dss_vae_amd.utils.model_utils import get_eval_info, get_lr_anneal, lr_transformer, update_lr
+    a = Namespace(lr=0.001, anneal_steps=100, lr_schedule="anneal", d_model=512, warmup=4000)
+    assert abs(get_lr_anneal(a, 50) - ((0.001 - 1e-5) * 0.5 + 1e-5)) < 1e-12 and get_lr_anneal(a, 500) == 1e-5
+    assert abs(lr_transformer(a, 10) - 0.1 * 10 / math.sqrt(512) * 10 / (4000 * math.sqrt(4000))) < 1e-15
+
+    class Opt:
+        param_groups = [{"lr": 0.0}]
+    assert update_lr(a, Opt, 49).param_groups[0]["lr"] == get_lr_anneal(a, 50)
+    a.lr_schedule = "fixed"
+    assert update_lr(a, Opt, 3).param_groups[0]["lr"] == 0.001
+    a.lr_schedule = "transformer"
+    assert update_lr(a, Opt, 9).param_groups[0]["lr"] == lr_transformer(a, 10)
+    args_to_yaml(str(tmp_path / "a.yaml"), a)
+    assert yaml_to_dict(str(tmp_path / "a.yaml"))["anneal_steps"] == 100
+    d = get_eval_info(Namespace(exp_name="x", model_dir=str(tmp_path / "m")), Namespace(model_select="SyntaxVAE2"), "Test")
+    assert d.endswith(os.path.join("SyntaxVAE2.x", "Test")) and os.path.isdir(d)

@@ -56,6 +56,19 @@ def test_training_driver_end_to_end(tmp_path):
         assert len(open(os.path.join(rec, f)).read().splitlines()) == 12
     base = os.path.dirname(out["model_file"])
     assert os.path.exists(os.path.join(base, "base_config.yaml")) and os.path.exists(os.path.join(base, "model_config.yaml"))
+    # test-mode entry of a driver: configs + checkpoint of the experiment -> model on the GPU -> decode
+    from dss_vae_amd.utils.model_utils import load_configs, load_model
+    pre_main, pre_model = load_configs(base)
+    assert pre_model.model_select == "SyntaxVAE2" and pre_main.batch_size == 8
+    m2 = load_model(pre_main, pre_model, check_dir=False)
+    sd2 = m2.state_dict()
+    for k, v in ck["state_dict"].items():
+        assert torch.equal(sd2[k].cpu(), v.cpu()), k
+    m2.eval()
+    dev = Dataset.from_bin_file(str(tmp_path / "dev.bin")).examples[:4]
+    with torch.no_grad():
+        res = m2.predict(dev)
+    assert len(res) == 4 and all(isinstance(r[0][0], list) for r in res)
 
 
 def _dp_driver_worker(rank, world, port, root, q):
