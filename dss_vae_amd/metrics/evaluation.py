@@ -83,3 +83,30 @@ def new_evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src"
     write_result(predict_to_plain(res["reference"]), res["gold_file"])
     res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
     return (res, res["predict"]) if ret_dec_result else res
+
+
+def evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", return_decode_result=False,
+             batch_size=None, out_dir=None):
+    """metrics/evaluation.py:119-184: like new_evaluate but in corpus-order batches (each sorted by -len), so the
+    references are collected in decode order instead of un-permuting the predictions"""
+    if batch_size is None:
+        batch_size = 50 if "eval_bs" not in model.args else model.args.eval_bs
+    from ..structs import Dataset
+    ref_examples, pred = [], []
+    t0 = time.time()
+    for batch in Dataset(examples).batch_iter(batch_size, shuffle=False):
+        batch.sort(key=lambda e: -len(getattr(e, sort_key)))
+        ref_examples.extend(batch)
+        pred.extend(decode(batch, model))
+    res = {"reference": prepare_ref(ref_examples, eval_tgt, model.vocab), "predict": pred, "oracle_accuracy": 0.0,
+           "use_time": time.time() - t0}
+    out_dir = "./" if out_dir is None else out_dir
+    if not os.path.exists(out_dir):
+        os.makedirs(out_dir)
+    res["input_file"], res["pred_file"], res["gold_file"] = (os.path.join(out_dir, n) for n in
+                                                             ("input.txt", "pred.txt", "gold.txt"))
+    write_result(predict_to_plain(prepare_ref(ref_examples, eval_src, model.vocab)), res["input_file"])
+    write_result(predict_to_plain(pred), res["pred_file"])
+    write_result(predict_to_plain(res["reference"]), res["gold_file"])
+    res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    return (res, pred) if return_decode_result else res

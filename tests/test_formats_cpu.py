@@ -169,3 +169,34 @@ def test_lr_helpers_and_yaml_args(tmp_path):
     assert yaml_to_dict(str(tmp_path / "a.yaml"))["anneal_steps"] == 100
     d = get_eval_info(Namespace(exp_name="x", model_dir=str(tmp_path / "m")), Namespace(model_select="SyntaxVAE2"), "Test")
     assert d.endswith(os.path.join("SyntaxVAE2.x", "Test")) and os.path.isdir(d)
+
+
+def test_metrics_tools(tmp_path):
+    """metrics/tools.py:35-164 helpers: nested decode-result shapes, pair splitting, BLEU over results, corpus stats"""
+    from dss_vae_amd.metrics import tools
+    v = VocabEntry()
+    for w in ("a", "b", "c"):
+        v.add(w)
+    exs = [PlainExample(src=["a", "b"], tgt=["c", "zzz"]), PlainExample(src=["c"], tgt=["a"])]
+    sem, syn = tools.split_examples(exs)
+    assert [e.src for e in sem] == [["a", "b"], ["c"]] and [e.src for e in syn] == [["c", "zzz"], ["a"]]
+    assert all(e.tgt is None for e in sem + syn)
+    assert tools.recovery_ref(syn, v, keep_origin=True) == [[["c", "zzz"]], [["a"]]]
+    assert tools.recovery_ref(syn, v) == [[["c", "<unk>"]], [["a"]]]
+    res = [[["a", "b", "c", "a", "b"]], [5]]
+    assert tools.to_plain([res]) == [["a", "b", "c", "a", "b"]]
+    assert tools.con_to_plain([[["x", "y"]]]) == ["x y"] and tools.reference_to_plain([[[[["x", "y"]]]]]) == ["x y"]
+    assert abs(tools.get_bleu_score([[["a", "b", "c", "a", "b"]]], [res]) - 100.0) < 1e-9
+    assert tools.get_bleu_score([[["c", "c", "c", "c", "c"]]], [res]) < 50.0
+    assert [len(b) for b in tools.prepare_input(exs * 3, batch_size=4)] == [4, 2]
+    assert tools.avg_length([["a"], ["a", "b", "c"]]) == 2.0
+    same = tools.unigram_divergence([["a", "b"]], [["b", "a"]], v)
+    diff = tools.unigram_divergence([["a", "a"]], [["c", "c"]], v)
+    assert abs(same) < 1e-12 and diff > 0.05 and tools.unigram_divergence([["a"]], [["c"]], v, dtype="kl") > 0
+    tj = tools.TagJudge(v)
+    assert tj.is_tag("a") and not tj.is_tag("never-seen")
+    f = str(tmp_path / "s.score")
+    tools.write_append_result(["x"], f)
+    tools.write_append_result([["y", "z"]], f)
+    tools.write_append_result({"k": 1.5}, f)
+    assert open(f).read().splitlines() == ["x", "y z", "k:1.500000"]

@@ -71,6 +71,49 @@ def test_training_driver_end_to_end(tmp_path):
     assert len(res) == 4 and all(isinstance(r[0][0], list) for r in res)
 
 
+def test_test_time_evaluators(tmp_path):
+    """metrics/vae_metrics.py:30-268 around the GPU decode path: reconstruction, prior generation statistics,
+    paraphrase (`sem` / `sem-only`), controlled generation and syntax transfer over `sentence \\t reference` files;
+    the reference's file names, one line per example, finite scores"""
+    from dss_vae_amd.metrics.vae_metrics import SyntaxVaeEvaluator
+    from dss_vae_amd.models import MODEL_CLS
+    from dss_vae_amd.train import build_model_params_
+    n_src, n_tgt = 120, 30
+    model = MODEL_CLS["SyntaxVAE2"](args=make_args(eval_bs=5, dev_item="ELBO", **TINY), vocab=product_vocab(n_src, n_tgt))
+    build_model_params_(model, seed=5)
+    model.cuda().eval()
+    exs = product_examples(make_examples(7, n_src, n_tgt, src_len=9, tree_len=27, fixed=False, seed=3))
+    pairs = tmp_path / "pairs"
+    pairs.mkdir()
+    others = exs[1:] + exs[:1]
+    (pairs / "dev.txt").write_text("".join(" ".join(a.src) + "\t" + " ".join(b.src) + "\n" for a, b in zip(exs, others)))
+    ev = SyntaxVaeEvaluator(model, str(tmp_path / "out"), batch_size=3, train_batch_size=4)
+    out = str(tmp_path / "out")
+
+    def lines(name):
+        return open(os.path.join(out, name)).read().splitlines()
+
+    track, res = ev.evaluate_reconstruction(exs, "rec")
+    assert len(lines("rec.pred")) == len(lines("rec.gold")) == 7 and 0.0 <= res["accuracy"] <= 100.0
+    assert sorted(lines("rec.gold")) == sorted(" ".join(e.src) for e in exs)
+    assert any(l.startswith("ELBO:") for l in lines("rec.score")) and "Loss" in track
+    gen = ev.evaluate_generation(exs, sample_size=6, eval_desc="gen")
+    assert len(lines("gen.text")) == 6 and gen["Gen AvgLen"] > 0 and gen["UnigramKL"] >= 0.0
+    for fn, desc in ((ev.evaluate_para, "para"), (ev.evaluate_pure_para, "pure-para")):
+        (ori_bleu, tgt_bleu), = fn(str(pairs), ["dev.txt"])
+        assert 0.0 <= ori_bleu <= 100.0 and 0.0 <= tgt_bleu <= 100.0
+        assert len(lines("dev.txt.%s.pred" % desc)) == len(lines("dev.txt.%s.ori" % desc)) == 7
+        assert lines("dev.txt.%s.tgt" % desc)[0] == " ".join(others[0].src)
+    score, = ev.evaluate_control(str(pairs), ["dev.txt"])
+    assert 0.0 <= float(score) <= 100.0 and len(lines("dev.txt.con.pred")) == 7
+    assert lines("dev.txt.con.input")[2] == " ".join(exs[2].src) and lines("con.score") == [score]
+    report, = ev.evaluate_style_transfer(str(pairs), ["dev.txt"])
+    assert report.count("bleu:") == 6
+    for suffix in ("pred", "tgt", "ori", "ss", "st", "sp"):
+        assert len(lines("dev.txt.transfer." + suffix)) == 7, suffix
+    assert not model.training
+
+
 def _dp_driver_worker(rank, world, port, root, q):
     import faulthandler
     import numpy as np
