@@ -192,7 +192,7 @@ def test_metrics_tools(tmp_path):
     assert tools.avg_length([["a"], ["a", "b", "c"]]) == 2.0
     same = tools.unigram_divergence([["a", "b"]], [["b", "a"]], v)
     diff = tools.unigram_divergence([["a", "a"]], [["c", "c"]], v)
-    assert abs(same) < 1e-12 and diff > 0.05 and tools.unigram_divergence([["a"]], [["c"]], v, dtype="kl") > 0
+    assert abs(same) < 1e-12 and diff > 0.05 and tools.unigram_divergence([["a"] * 10], [["c"] * 10], v, dtype="kl") > 0.5
     tj = tools.TagJudge(v)
     assert tj.is_tag("a") and not tj.is_tag("never-seen")
     f = str(tmp_path / "s.score")
