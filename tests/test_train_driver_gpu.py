@@ -69,6 +69,21 @@ def test_training_driver_end_to_end(tmp_path):
     with torch.no_grad():
         res = m2.predict(dev)
     assert len(res) == 4 and all(isinstance(r[0][0], list) for r in res)
+    # bin/test.py::test_vae over the experiment's checkpoint: mode 0 (dev / test reconstruction + generation
+    # statistics) and mode 4 (syntax transfer over a pair file)
+    from dss_vae_amd.bin.test import test_vae
+    pre_main.test_file = pre_main.dev_file
+    rep = test_vae(pre_main, pre_model, input_mode=0)
+    for f in ("dev.pred", "dev.gold", "dev.score", "test.pred", "gen.text", "gen.score"):
+        assert os.path.exists(os.path.join(rep["out_dir"], f)), f
+    assert rep["out_dir"].endswith(os.path.join("SyntaxVAE2.t", "Test")) and rep["gen"]["Gen AvgLen"] > 0
+    (tmp_path / "pairs").mkdir()
+    (tmp_path / "pairs" / "dev.para.txt").write_text(
+        "".join(" ".join(a.src) + "\t" + " ".join(b.src) + "\n" for a, b in zip(dev, dev[1:] + dev[:1])))
+    rep = test_vae(pre_main, pre_model, input_mode=4, para_eval_dir=str(tmp_path / "pairs"), model=m2)
+    assert "unmatch" not in rep and rep["match"][0].count("bleu:") == 6
+    with pytest.raises(ValueError):
+        test_vae(pre_main, pre_model, input_mode=2)
 
 
 def test_test_time_evaluators(tmp_path):
