@@ -17,7 +17,8 @@ import sys
 NAMES = ["gemm_store_kernel", "gemm_group_kernel", "dssvae_zero2d_kernel", "linear_lse_kernel", "linear_dlogits_kernel", "gru_fwd_kernel", "gru_bwd_kernel",
          "adam_kernel", "sumsq_kernel", "softmax_grad_kernel", "colsum_kernel", "lse_combine_kernel",
          "picked_logit_kernel", "onehot_sub_kernel", "embed_scatter_kernel", "embed_gather_kernel",
-         "reparam_kl_fwd_kernel", "reparam_kl_bwd_kernel", "greedy_decode_kernel"]
+         "reparam_kl_fwd_kernel", "reparam_kl_bwd_kernel", "greedy_decode_kernel", "skinny_kernel<true", "skinny_kernel<false",
+         "skinny_gru_kernel", "combine_gather_kernel"]
 PAT = re.compile("|".join(NAMES))
 csv.field_size_limit(1 << 30)
 
