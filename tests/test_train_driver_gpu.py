@@ -129,7 +129,7 @@ def test_test_time_evaluators(tmp_path):
     assert not model.training
 
 
-def _dp_driver_worker(rank, world, port, root, q):
+def _dp_driver_worker(rank, world, port, root, q, warm_up=0):
     import faulthandler
     import numpy as np
     import torch.distributed as dist
@@ -146,7 +146,7 @@ def _dp_driver_worker(rank, world, port, root, q):
                               model_dir=os.path.join(root, "models"), exp_name="dp", task_type="SyntaxVAE2",
                               start_iter=0, batch_size=4, log_every=2, dev_every=3, lr=0.0005, lr_decay=0.8,
                               patience=1, clip_grad=5.0, reset_optimizer=False, mode="train", seed=None)
-        model_args = make_args(warm_up=0, eval_bs=5, dev_item="ELBO", adv_train=True, **TINY)
+        model_args = make_args(warm_up=warm_up, eval_bs=5, dev_item="ELBO", adv_train=True, **TINY)
         out = training(main_args, model_args, max_iters=7)  # 21 sentences / (4 x 2): tail batch of 5 = 3 + 2
         flat = out["optimizer"].flat.detach().double().cpu()
         both = [torch.zeros_like(flat) for _ in range(world)]
@@ -167,10 +167,12 @@ def _dp_driver_worker(rank, world, port, root, q):
         dist.destroy_process_group()
 
 
-def test_training_driver_two_ranks(tmp_path):
+@pytest.mark.parametrize("warm_up", [0, 4], ids=["past_warm_up", "crossing_warm_up"])
+def test_training_driver_two_ranks(tmp_path, warm_up):
     """the driver under data parallel (two ranks on the one GPU, gloo): differently seeded ranks end with
     bit-identical replicas after 7 adversarial iterations incl. an unequal tail batch, dev evaluation and
-    rank 0's checkpoint / schedule broadcast"""
+    rank 0's checkpoint / schedule broadcast.  Second case: the -adv term joins the loss at iteration 5
+    (train_iter > warm_up), i.e. the autograd graph of the main pass changes under the learned bucket schedule."""
     import socket
     import torch.multiprocessing as mp
     from dss_vae_amd.structs import Dataset
@@ -186,7 +188,7 @@ def test_training_driver_two_ranks(tmp_path):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_driver_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_driver_worker, args=(r, 2, port, str(tmp_path), q, warm_up)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=200) for _ in procs]
