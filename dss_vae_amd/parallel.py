@@ -40,10 +40,12 @@ class GradBuckets(object):
     only once every lower-numbered bucket has been sent, so all ranks issue their collectives in ONE
     fixed order whatever order autograd fires the hooks in (RCCL requires identical issue order on
     every rank; the fired sets are identical on all ranks because the graphs are).  A gradient that
-    arrives for a bucket that is already on the wire cannot be repaired and raises.  `finish()` sends
-    whatever has not been sent and makes the averaged gradients visible to the current stream.  A bucket
-    none of whose parameters got a gradient in the last step of this kind is not sent at all (its slice
-    is zero on every rank).
+    arrives for a bucket that is already on the wire (or was skipped) -- the graph of this step differs from
+    the last one of its kind -- is taken aside by `intercept()` (a tensor hook, before accumulation),
+    averaged on its own at `finish()` and added to the bucket's averaged slice; the next step of the kind
+    expects it.  `finish()` sends whatever has not been sent and makes the averaged gradients visible to
+    the current stream.  A bucket none of whose parameters got a gradient in the last step of this kind is
+    not sent at all (its slice is zero on every rank).
     """
 
     def __init__(self, flat_grad, params, offsets, bucket_elems, group=None, overlap=True):
@@ -86,10 +88,11 @@ class GradBuckets(object):
         self.next = 0      # buckets [0, next) have been sent
         self.works = []
         self.sent_early = 0
+        self.late = {}     # parameter index -> gradient that arrived after its bucket was dealt with
 
     def _send(self, b):
         lo, hi, idx = self.buckets[b]
-        if self.known is not None and not any(i in self.known for i in idx):
+        if self.known is not None and not any(i in self.known or i in self.fired for i in idx):
             # no parameter of this bucket gets a gradient in this kind of step (frozen adversaries in a main
             # pass -- 60 % of the buffer at V = 30k -- or everything but the adversaries in a discriminator
             # pass): its slice is zero on every rank, the average is zero, nothing to send.  The fired sets
@@ -118,22 +121,28 @@ class GradBuckets(object):
         else:
             self.works.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
+    def intercept(self, i, g):
+        """tensor hook of parameter i (runs before the gradient is accumulated): a gradient for a bucket that
+        has already been sent or skipped is kept aside and replaced by zeros, so the bucket's averaged slice
+        stays intact; `finish()` averages it separately.  Returns the replacement or None (no change)."""
+        if g is None or self.expect is None or self.bucket_of[i] >= self.next:
+            return None
+        held = self.late.get(i)
+        self.late[i] = g.detach().clone() if held is None else held.add_(g.detach())
+        return torch.zeros_like(g)
+
     def mark_ready(self, i):
         self.fired.add(i)
         if self.expect is None:
-            if self.known is not None and i not in self.known and \
-                    not any(k in self.known for k in self.buckets[self.bucket_of[i]][2]):
-                raise RuntimeError(
-                    "gradient of parameter %d arrived for a bucket that this kind of step (tag %r) does not "
-                    "all-reduce: the autograd graph differs from the previous one; give the steps different tags"
-                    % (i, self.tag))
-            return
+            return  # everything goes at finish(); _send() keeps every bucket that fired this step
         b = self.bucket_of[i]
         if b < self.next:
+            if i in self.late:
+                return
             raise RuntimeError(
-                "gradient of parameter %d arrived after its bucket was all-reduced: the autograd graph of this "
-                "step (tag %r) differs from the previous one; set DSSVAE_DP_OVERLAP=0 or give the steps "
-                "different tags" % (i, self.tag))
+                "gradient of parameter %d arrived after its bucket was all-reduced and no tensor hook routed it "
+                "through GradBuckets.intercept(): register it (FlatAdam does), set DSSVAE_DP_OVERLAP=0 or give "
+                "the steps different tags (tag %r)" % (i, self.tag))
         if i in self.expect:
             self.pending[b] -= 1
             while self.next < len(self.buckets) and self.pending[self.next] <= 0:
@@ -157,4 +166,18 @@ class GradBuckets(object):
         if self.comm is not None:
             torch.cuda.current_stream().wait_stream(self.comm)
         self.works = []
+        for i in sorted(self.late):  # same graph on every rank => same late set, reduced in index order
+            g = self.late[i]
+            if self.backend == "nccl":
+                dist.all_reduce(g, op=dist.ReduceOp.AVG, group=self.group)
+            elif g.is_cuda:
+                host = g.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                g.copy_(host.div_(self.world))
+            else:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+                g.div_(self.world)
+            off = self.offsets[i]
+            self.flat[off:off + g.numel()].add_(g.reshape(-1))
+        self.late = {}
         self.expected[self.tag] = frozenset(self.fired)

@@ -93,6 +93,9 @@ class FlatAdam(object):
     def _on_arrive(self, i, g):
         if g is not None and self.params[i].requires_grad:
             self.fired.add(i)
+            if self.buckets is not None:
+                return self.buckets.intercept(i, g)  # None unless the gradient is late for its bucket
+        return None
 
     def zero_grad(self, tag="main"):
         """tag: kind of step that follows (steps of one kind share an autograd graph shape; the
