@@ -194,8 +194,16 @@ class TwoEncoderVAE(BaseVAE):
         sem_ret, syn_ret = self.latent_for_init(ret=sem_ret), self.latent_for_init(ret=syn_ret)
         ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
         ret["res"] = self.decode_to_sentence(ret=ret)
-        ret["ori syn"] = self.predict_syntax(hidden=sem_ret["syn_hidden"], predictor=predictor)
-        ret["ref syn"] = self.predict_syntax(hidden=syn_ret["syn_hidden"], predictor=predictor)
+        h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
+        n = h_ori.size(1)
+        if h_ref.size(1) == n and 2 * n <= 128:
+            # the two 100-step tree decodes are launch-bound and independent row by row: one decode of 2B rows
+            # (still within the decode-batch kernels' 128 rows, so every row sees the same arithmetic)
+            both = self.predict_syntax(hidden=torch.cat((h_ori, h_ref), dim=1), predictor=predictor)
+            ret["ori syn"], ret["ref syn"] = both[:n], both[n:]
+        else:
+            ret["ori syn"] = self.predict_syntax(hidden=h_ori, predictor=predictor)
+            ret["ref syn"] = self.predict_syntax(hidden=h_ref, predictor=predictor)
         return ret
 
 
