@@ -94,11 +94,31 @@ class BaseVAE(nn.Module):
         return self.decode_to_sentence(ret=ret)
 
     def generating(self, sample_num, batch_size=50):
+        """base_vae.py:69-85.  Software-pipelined: the token matrix of batch k leaves for pinned host memory
+        behind its decode, batch k+1 is enqueued, and only then does the host wait for batch k and turn ids into
+        words -- the GPU decodes while the host converts.  Noise is drawn in the same order as without."""
         batch_size = batch_size if sample_num >= batch_size else sample_num
-        res = []
+        res, pending = [], None
         for _ in range(int((sample_num - 1) / batch_size) + 1):
-            res.extend(self.decode_to_sentence(self.latent_for_init(self.sample_latent(batch_size))))
+            toks = self.decode_tokens(self.latent_for_init(self.sample_latent(batch_size))).t()
+            host = torch.empty(toks.shape, dtype=toks.dtype, pin_memory=True)
+            host.copy_(toks, non_blocking=True)
+            done = torch.cuda.Event()
+            done.record()
+            if pending is not None:
+                res.extend(self._to_sentences(*pending))
+            pending = (host, done)
+        if pending is not None:
+            res.extend(self._to_sentences(*pending))
         return res
+
+    def _to_sentences(self, host_tokens, done):
+        done.synchronize()
+        out = []
+        for hyp in host_tokens.tolist():
+            words = id2word(hyp, self.vocab.src)
+            out.append([[words], [len(words)]])
+        return out
 
     unsupervised_generating = generating
 
