@@ -193,18 +193,35 @@ class TwoEncoderVAE(BaseVAE):
         syn_ret = self.hidden_to_latent(self.encode_to_hidden(syn_ref, need_sort=True), is_sampling=self.training)
         sem_ret, syn_ret = self.latent_for_init(ret=sem_ret), self.latent_for_init(ret=syn_ret)
         ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
-        ret["res"] = self.decode_to_sentence(ret=ret)
+        # the sentence tokens leave for pinned host memory behind their decode; they are turned into words
+        # below while the GPU runs the tree decodes
+        sent_dev = self.decode_tokens(ret).t()
+        sent_tokens = torch.empty(sent_dev.shape, dtype=sent_dev.dtype, pin_memory=True)
+        sent_tokens.copy_(sent_dev, non_blocking=True)
+        sent_done = torch.cuda.Event()
+        sent_done.record()
         h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
         n = h_ori.size(1)
         if h_ref.size(1) == n and 2 * n <= 128:
             # the two 100-step tree decodes are launch-bound and independent row by row: one decode of 2B rows
             # (still within the decode-batch kernels' 128 rows, so every row sees the same arithmetic)
-            both = self.predict_syntax(hidden=torch.cat((h_ori, h_ref), dim=1), predictor=predictor)
-            ret["ori syn"], ret["ref syn"] = both[:n], both[n:]
+            tree_tokens = [predictor.predict(torch.cat((h_ori, h_ref), dim=1))]
         else:
-            ret["ori syn"] = self.predict_syntax(hidden=h_ori, predictor=predictor)
-            ret["ref syn"] = self.predict_syntax(hidden=h_ref, predictor=predictor)
+            tree_tokens = [predictor.predict(h_ori), predictor.predict(h_ref)]
+        sent_done.synchronize()
+        ret["res"] = self._words(sent_tokens, self.vocab.src)
+        trees = [t for tok in tree_tokens for t in self._words(tok.t(), self.vocab.tgt)]
+        ret["ori syn"], ret["ref syn"] = trees[:n], trees[n:]
         return ret
+
+    @staticmethod
+    def _words(tokens, vocab):
+        """token matrix [B, max_len] -> [[[words], [len]], ...] cut at the first </s>"""
+        out = []
+        for hyp in tokens.tolist():
+            res = id2word(hyp, vocab)
+            out.append([[res], [len(res)]])
+        return out
 
 
 class SyntaxVAE(TwoEncoderVAE):
