@@ -52,14 +52,33 @@ def decode(examples, model):
     return res
 
 
+def decode_batches(batches, model):
+    """decode(b, model) for every batch, in order; with a model that offers predict_async / finish_predict the
+    loop is software-pipelined (batch k+1 is on the GPU while the host turns the ids of batch k into words)"""
+    if not (hasattr(model, "predict_async") and hasattr(model, "finish_predict")):
+        return [r for b in batches for r in decode(b, model)]
+    was_training = model.training
+    model.eval()
+    out, pending = [], None
+    with torch.no_grad():
+        for b in batches:
+            handle = model.predict_async(b)
+            if pending is not None:
+                out.extend(model.finish_predict(pending))
+            pending = handle
+        if pending is not None:
+            out.extend(model.finish_predict(pending))
+    if was_training:
+        model.train()
+    return out
+
+
 def prediction(examples, model, sort_key="src", eval_src="src", out_dir=None, batch_size=None):
     if batch_size is None:
         batch_size = 50 if "eval_bs" not in model.args else model.args.eval_bs
     batches, ids = batchify_examples(examples, sort_key=sort_key, batch_size=batch_size)
     t0 = time.time()
-    cache = []
-    for b in batches:
-        cache.extend(decode(b, model))
+    cache = decode_batches(batches, model)
     use_time = time.time() - t0
     pred = [None] * len(cache)
     for new_id, ori in enumerate(ids):
@@ -94,10 +113,12 @@ def evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", re
     from ..structs import Dataset
     ref_examples, pred = [], []
     t0 = time.time()
+    batches = []
     for batch in Dataset(examples).batch_iter(batch_size, shuffle=False):
         batch.sort(key=lambda e: -len(getattr(e, sort_key)))
         ref_examples.extend(batch)
-        pred.extend(decode(batch, model))
+        batches.append(batch)
+    pred = decode_batches(batches, model)
     res = {"reference": prepare_ref(ref_examples, eval_tgt, model.vocab), "predict": pred, "oracle_accuracy": 0.0,
            "use_time": time.time() - t0}
     out_dir = "./" if out_dir is None else out_dir

@@ -93,6 +93,22 @@ class BaseVAE(nn.Module):
         ret = self.latent_for_init(ret=ret)
         return self.decode_to_sentence(ret=ret)
 
+    def predict_async(self, examples):
+        """predict() in two halves for callers that decode batch after batch (metrics/evaluation.py): this one
+        enqueues encode -> latent -> greedy decode and the copy of the token matrix to pinned host memory and
+        returns a handle; `finish_predict(handle)` waits for that copy only and returns what predict() returns.
+        Enqueue batch k+1 before finishing batch k and the host's id -> word work runs under the GPU's decode."""
+        ret = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(examples), is_sampling=self.training))
+        toks = self.decode_tokens(ret).t()
+        host = torch.empty(toks.shape, dtype=toks.dtype, pin_memory=True)
+        host.copy_(toks, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        return host, done
+
+    def finish_predict(self, handle):
+        return self._to_sentences(*handle)
+
     def generating(self, sample_num, batch_size=50):
         """base_vae.py:69-85.  Software-pipelined: the token matrix of batch k leaves for pinned host memory
         behind its decode, batch k+1 is enqueued, and only then does the host wait for batch k and turn ids into

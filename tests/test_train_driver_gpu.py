@@ -127,6 +127,12 @@ def test_test_time_evaluators(tmp_path):
     for suffix in ("pred", "tgt", "ori", "ss", "st", "sp"):
         assert len(lines("dev.txt.transfer." + suffix)) == 7, suffix
     assert not model.training
+    # the pipelined decode loop of the evaluators returns what predict() returns batch by batch
+    from dss_vae_amd.metrics.evaluation import decode_batches
+    batches = [sorted(exs[:3], key=lambda e: -len(e.src)), sorted(exs[3:], key=lambda e: -len(e.src))]
+    with torch.no_grad():
+        want = model.predict(batches[0]) + model.predict(batches[1])
+    assert decode_batches(batches, model) == want
 
 
 def _dp_driver_worker(rank, world, port, root, q, warm_up=0):
