@@ -202,7 +202,7 @@ inline unsigned grid_for(int64_t n, int block = 256, int cap = 2048) {
 
 }  // namespace
 
-extern "C" int dssvae_abi_version(void) { return 1; }
+extern "C" int dssvae_abi_version(void) { return DSSVAE_ABI_VERSION; }
 
 extern "C" int dssvae_device_cus(int* n) {
     if (!n) return DSSVAE_EINVAL;

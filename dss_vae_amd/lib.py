@@ -13,6 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
+ABI_VERSION = 2  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -108,6 +109,9 @@ def load():
         for name, (argtypes, restype) in _SIGNATURES.items():
             fn = getattr(lib, name)
             fn.argtypes, fn.restype = argtypes, restype
+        if lib.dssvae_abi_version() != ABI_VERSION:
+            raise RuntimeError("dss_vae_amd: %s is ABI version %d, this package binds version %d -- rebuild it "
+                               "(make -C dss_vae_amd/csrc)" % (LIB_PATH, lib.dssvae_abi_version(), ABI_VERSION))
         _lib = lib
     return _lib
 

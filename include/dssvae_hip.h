@@ -28,6 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
+#define DSSVAE_ABI_VERSION 2 /* 2: dssvae_sumsq takes a partials scratch; dssvae_skinny_gru_step; dbias in dssvae_gru_bwd_inst */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
