@@ -125,6 +125,10 @@ def training(main_args, model_args, model=None, max_iters=None):
                 dev_acc = eval_result_dict[evaluator.score_item]
                 if isinstance(dev_acc, torch.Tensor):
                     dev_acc = dev_acc.sum().item()
+                if world > 1:  # rank 0's score (the one whose files were written) drives every replica's history
+                    acc_t = torch.tensor([float(dev_acc)], device="cuda", dtype=torch.float64)
+                    dist.broadcast(acc_t, 0)
+                    dev_acc = float(acc_t.item())
                 print("\r[Iter %d] %s %s=%.3f took %d s" % (train_iter, task_type, evaluator.score_item, dev_acc,
                                                             eval_result_dict["EVAL TIME"]), file=sys.stdout)
                 is_better = (history_scores == []) or dev_acc > max(history_scores)

@@ -36,6 +36,17 @@ def corpus_bleu(list_of_references, hypotheses, max_n=4):
     return bp * math.exp(sum(math.log(float(a) / b) for a, b in zip(num, den)) / max_n)
 
 
+def evaluate_lines(pred_lines, gold_lines_list):
+    """evaluate_file on lines that were never written: same tokenisation (strip, split on one blank), so a
+    rank that keeps its dev decode in memory scores exactly what the writing rank reads back."""
+    hyps = [line.strip().split(" ") for line in pred_lines]
+    refs = [[] for _ in hyps]
+    for lines in gold_lines_list:
+        for i, line in enumerate(lines):
+            refs[i].append(line.strip().split(" "))
+    return 100.0 * corpus_bleu(refs, hyps)
+
+
 def evaluate_file(pred_file, gold_files):
     """BleuScoreMetric.evaluate_file: one hypothesis per line, references line-aligned; x100."""
     with open(pred_file) as f:

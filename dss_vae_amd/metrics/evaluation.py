@@ -73,7 +73,9 @@ def decode_batches(batches, model):
     return out
 
 
-def prediction(examples, model, sort_key="src", eval_src="src", out_dir=None, batch_size=None):
+def prediction(examples, model, sort_key="src", eval_src="src", out_dir=None, batch_size=None, write=True):
+    """write=False keeps input/pred lines in the result ("input_lines" / "pred_lines") and touches no file:
+    under data parallel only rank 0 writes, the other replicas score what they decoded in memory"""
     if batch_size is None:
         batch_size = 50 if "eval_bs" not in model.args else model.args.eval_bs
     batches, ids = batchify_examples(examples, sort_key=sort_key, batch_size=batch_size)
@@ -84,28 +86,34 @@ def prediction(examples, model, sort_key="src", eval_src="src", out_dir=None, ba
     for new_id, ori in enumerate(ids):
         pred[ori] = cache[new_id]
     out_dir = "./" if out_dir is None else out_dir
-    if not os.path.exists(out_dir):
-        os.makedirs(out_dir)
     res = {"predict": pred, "oracle_accuracy": 0.0, "use_time": use_time,
-           "input_file": os.path.join(out_dir, "input.txt"), "pred_file": os.path.join(out_dir, "pred.txt")}
-    write_result(predict_to_plain(prepare_ref(examples, eval_src, model.vocab)), res["input_file"])
-    write_result(predict_to_plain(pred), res["pred_file"])
+           "input_file": os.path.join(out_dir, "input.txt"), "pred_file": os.path.join(out_dir, "pred.txt"),
+           "input_lines": predict_to_plain(prepare_ref(examples, eval_src, model.vocab)),
+           "pred_lines": predict_to_plain(pred)}
+    if write:
+        os.makedirs(out_dir, exist_ok=True)
+        write_result(res["input_lines"], res["input_file"])
+        write_result(res["pred_lines"], res["pred_file"])
     return res
 
 
 def new_evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", ret_dec_result=False, batch_size=None,
-                 out_dir=None):
-    res = prediction(examples, model, sort_key, eval_src, out_dir, batch_size)
+                 out_dir=None, write=True):
+    res = prediction(examples, model, sort_key, eval_src, out_dir, batch_size, write=write)
     res["reference"] = prepare_ref(examples, eval_tgt, model.vocab)
     out_dir = "./" if out_dir is None else out_dir
     res["gold_file"] = os.path.join(out_dir, "gold.txt")
-    write_result(predict_to_plain(res["reference"]), res["gold_file"])
-    res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    res["gold_lines"] = predict_to_plain(res["reference"])
+    if write:
+        write_result(res["gold_lines"], res["gold_file"])
+        res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    else:
+        res["accuracy"] = bleu.evaluate_lines(res["pred_lines"], [res["gold_lines"]])
     return (res, res["predict"]) if ret_dec_result else res
 
 
 def evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", return_decode_result=False,
-             batch_size=None, out_dir=None):
+             batch_size=None, out_dir=None, write=True):
     """metrics/evaluation.py:119-184: like new_evaluate but in corpus-order batches (each sorted by -len), so the
     references are collected in decode order instead of un-permuting the predictions"""
     if batch_size is None:
@@ -122,12 +130,15 @@ def evaluate(examples, model, sort_key="src", eval_src="src", eval_tgt="src", re
     res = {"reference": prepare_ref(ref_examples, eval_tgt, model.vocab), "predict": pred, "oracle_accuracy": 0.0,
            "use_time": time.time() - t0}
     out_dir = "./" if out_dir is None else out_dir
-    if not os.path.exists(out_dir):
-        os.makedirs(out_dir)
     res["input_file"], res["pred_file"], res["gold_file"] = (os.path.join(out_dir, n) for n in
                                                              ("input.txt", "pred.txt", "gold.txt"))
-    write_result(predict_to_plain(prepare_ref(ref_examples, eval_src, model.vocab)), res["input_file"])
-    write_result(predict_to_plain(pred), res["pred_file"])
-    write_result(predict_to_plain(res["reference"]), res["gold_file"])
-    res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    res["input_lines"] = predict_to_plain(prepare_ref(ref_examples, eval_src, model.vocab))
+    res["pred_lines"], res["gold_lines"] = predict_to_plain(pred), predict_to_plain(res["reference"])
+    if write:
+        os.makedirs(out_dir, exist_ok=True)
+        for key in ("input", "pred", "gold"):
+            write_result(res[key + "_lines"], res[key + "_file"])
+        res["accuracy"] = bleu.evaluate_file(res["pred_file"], res["gold_file"])
+    else:
+        res["accuracy"] = bleu.evaluate_lines(res["pred_lines"], [res["gold_lines"]])
     return (res, pred) if return_decode_result else res

@@ -35,8 +35,7 @@ class SyntaxVaeEvaluator(object):
             for batch in batches:
                 track = update_tracker(model.get_loss(batch, step), track)
         if self.write_down:
-            if not os.path.exists(self.out_dir):
-                os.makedirs(self.out_dir)
+            os.makedirs(self.out_dir, exist_ok=True)
             write_result(track, fname=os.path.join(self.out_dir, eval_desc + ".score"))
         model.train(training)
         return track
@@ -46,7 +45,7 @@ class SyntaxVaeEvaluator(object):
         training = model.training
         model.eval()
         res = new_evaluate(self.eval_set, model, sort_key=self.sort_key, eval_tgt=self.eval_tgt, batch_size=self.batch_size,
-                           out_dir=os.path.join(self.out_dir, eval_desc))
+                           out_dir=os.path.join(self.out_dir, eval_desc), write=self.write_down)
         model.train(training)
         return {"BLEU": res["accuracy"], "EVAL TIME": res["use_time"],
                 "EVAL SPEED": len(self.eval_set) / max(res["use_time"], 1e-9)}
@@ -59,9 +58,9 @@ class SyntaxVaeEvaluator(object):
         training = model.training
         model.eval()
         res = new_evaluate(self.eval_set, model, sort_key=self.sort_key, eval_tgt=self.eval_tgt, batch_size=self.batch_size,
-                           out_dir=os.path.join(self.out_dir, eval_desc))
+                           out_dir=os.path.join(self.out_dir, eval_desc), write=self.write_down)
         tgt_bleu = res["accuracy"]
-        ori_bleu = bleu.evaluate_file(res["pred_file"], res["input_file"])
+        ori_bleu = bleu.evaluate_lines(res["pred_lines"], [res["input_lines"]])
         model.train(training)
         return {"TGT BLEU": tgt_bleu, "ORI BLEU": ori_bleu, "TGT_ORI_RATE": tgt_bleu / max(ori_bleu, 1e-9),
                 "EVAL TIME": res["use_time"], "EVAL SPEED": len(self.eval_set) / max(res["use_time"], 1e-9)}

@@ -194,8 +194,8 @@ class BaseVAE(nn.Module):
 
     def save(self, path):
         d = os.path.dirname(path)
-        if d and not os.path.exists(d):
-            os.makedirs(d)
+        if d:
+            os.makedirs(d, exist_ok=True)
         if not os.path.exists(path + ".config"):
             with open(path + ".config", "w") as f:
                 f.write("{}".format(self.base_information()))
