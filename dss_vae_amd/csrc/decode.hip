@@ -6,8 +6,38 @@
 // kernels on the caller's stream: no allocation, no synchronisation, no device->host traffic (the
 // reference does a topk + .cpu() per step), so the whole decode is also capturable in a HIP graph.
 #include "common.h"
+#include <mutex>
+
+// Scratch of the no-allocation entry point (dssvae_greedy_decode_noalloc): the loop's whole workspace lives in
+// this file-scope device array, one copy per GPU, held until the process ends.  In host code the array's NAME is
+// a host-side stand-in, not a device address: the address is taken once per device with hipGetSymbolAddress and
+// only that pointer is ever handed to kernels / copies.
+static __device__ __align__(256) unsigned char scratch[DSSVAE_DECODE_NOALLOC_BYTES];
 
 namespace {
+constexpr int MAX_DEVICES = 64;
+void* g_scratch_ptr[MAX_DEVICES];
+std::mutex g_scratch_mu;
+
+// device address of `scratch` on the current device (resolved on the first call per device, with that device
+// current); returns a hipError_t / DSSVAE_EINVAL on failure
+int scratch_address(void** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= MAX_DEVICES) return DSSVAE_EINVAL;
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return (int)e;
+        if (!ptr) return DSSVAE_EINVAL;
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return DSSVAE_OK;
+}
+
 struct Ws {
     float* x;        // [B,E]   embedding rows of the current tokens
     float* gi;       // [B,3H]
@@ -158,4 +188,22 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
         }
     }
     return DSSVAE_OK;
+}
+
+// The same loop with its workspace in the library's own per-GPU `scratch` array: no hipMalloc / hipFree, no
+// allocating routine; shapes whose workspace exceeds DSSVAE_DECODE_NOALLOC_BYTES are rejected (DSSVAE_ETOOBIG).
+// The loop overwrites every scratch region before reading it (h from h0, tok from sos, x from the gather, the
+// partials by the arg-max kernel of each step), so nothing has to be cleared between calls; calls that overlap
+// on one GPU (two streams) share the array and race.
+extern "C" int dssvae_greedy_decode_noalloc(const dssvae_decode_params* p, const float* h0, int B, int max_len,
+                                            int64_t sos_id, int n_split, int64_t* tokens, float* h_final,
+                                            void* stream) {
+    if (!p || B <= 0 || n_split <= 0) return DSSVAE_EINVAL;
+    const int64_t need = dssvae_greedy_decode_workspace_bytes(B, p->E, p->H, p->n_layers, n_split, p->V);
+    if (need < 0) return (int)need;
+    if (need > (int64_t)DSSVAE_DECODE_NOALLOC_BYTES) return DSSVAE_ETOOBIG;
+    void* ptr = nullptr;
+    const int rc = scratch_address(&ptr);
+    if (rc != DSSVAE_OK) return rc;
+    return dssvae_greedy_decode(p, h0, B, max_len, sos_id, n_split, tokens, h_final, ptr, need, stream);
 }

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 2  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 3  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -45,6 +45,7 @@ class GemmProblem(C.Structure):
 
 
 DECODE_MAX_LAYERS = 4
+DECODE_NOALLOC_BYTES = 16 << 20
 
 
 class DecodeParams(C.Structure):
@@ -89,6 +90,7 @@ _SIGNATURES = {
     "dssvae_skinny_argmax": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _P, _P, _P], _I),
     "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
     "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),
+    "dssvae_greedy_decode_noalloc": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P], _I),
     "dssvae_sumsq": ([_P, _L, _P, _P, _P], _I),
     "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P], _I),
 }

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 2 /* 2: dssvae_sumsq takes a partials scratch; dssvae_skinny_gru_step; dbias in dssvae_gru_bwd_inst */
+#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -274,6 +274,16 @@ int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, 
 int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, int B, int max_len,
                          int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
                          int64_t workspace_bytes, void* stream);
+/* dssvae_greedy_decode without a workspace argument and without any allocation.  NO COUNTERPART IN THE
+ * REFERENCE: it exists for callers that cannot call hipMalloc (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid allocation).  The loop's workspace is a file-scope device array inside the
+ * library (DSSVAE_DECODE_NOALLOC_BYTES per GPU the library runs on, held until the process ends); a shape whose
+ * dssvae_greedy_decode_workspace_bytes(...) exceeds it returns DSSVAE_ETOOBIG with nothing launched (16 MiB
+ * covers a decode batch of 128 at E=300, H=600, 2 layers, V=30000).  Same results as dssvae_greedy_decode.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+#define DSSVAE_DECODE_NOALLOC_BYTES (16u << 20)
+int dssvae_greedy_decode_noalloc(const dssvae_decode_params* params, const float* h0, int B, int max_len,
+                                 int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Optimiser over flat fp32 buffers (bin/train.py:124-126, utils/model_utils.py:195):
