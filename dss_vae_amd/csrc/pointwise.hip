@@ -180,7 +180,10 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, const float* __restrict__ sumsq, float max_norm,
-                            const float* __restrict__ live) {
+                            const float* __restrict__ live, const int32_t* __restrict__ skip) {
+    // a persistent launch of this step timed out waiting for a peer (its results are garbage): the whole
+    // update is dropped on device, before the host gets to read the error word
+    if (skip && skip[0] != 0) return;
     float clip = 1.f;
     if (sumsq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
     const float step = lr / bc1;
@@ -319,12 +322,12 @@ extern "C" int dssvae_sumsq(const float* g, int64_t n, float* partials, float* s
 
 extern "C" int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                                 float beta2, float eps, int step, const float* sumsq, float max_norm,
-                                const float* grad_scale_mask, void* stream) {
+                                const float* grad_scale_mask, const int32_t* skip_flag, void* stream) {
     if (!p || !g || !m || !v || n <= 0 || step < 1) return DSSVAE_EINVAL;
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask);
+                       beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask, skip_flag);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -422,6 +422,9 @@ def _col_chunks(M, N):
 # step at 2 streams, but concurrent kernels blur the per-kernel durations the roofline report is built on,
 # so the default stays at one stream.
 CE_STREAMS = max(1, int(_os.environ.get("DSSVAE_CE_STREAMS", "1")))
+# the fused CE schedule scales stored unit gradients by row 0's upstream gradient (the caller's contract: all rows
+# receive the same one); with this flag every backward verifies it (one device sync each: tests / debugging only)
+CHECK_UNIFORM_UPSTREAM = _os.environ.get("DSSVAE_CHECK_UNIFORM", "0") == "1"
 _SIDE = {}
 
 
@@ -550,9 +553,14 @@ class _LinearCEFn(Function):
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         if ctx.fused:
             # every row has the same upstream gradient (the caller's contract): scale the unit gradients
+            if ctx.unit_grads is None:
+                raise RuntimeError("linear_ce(uniform_upstream=True) keeps its gradients for ONE backward pass "
+                                   "(retain_graph / a second backward is not supported on this schedule)")
             dx, dW, db = ctx.unit_grads
             ctx.unit_grads = None
             c = g[:1]
+            if CHECK_UNIFORM_UPSTREAM and not bool((g == c).all()):  # DSSVAE_CHECK_UNIFORM=1: tests / debugging
+                raise RuntimeError("linear_ce(uniform_upstream=True): rows received different upstream gradients")
             dxh = dxe = None
             if dx is not None:
                 dx.mul_(g.unsqueeze(1))
@@ -734,13 +742,21 @@ def _pack(insts):
 _PERSISTENT_ERR = {}
 
 
+def persistent_error_word(device):
+    """sticky per-device int32: number of persistent launches that timed out since the last check"""
+    key = torch.device(device).index
+    if key is None:
+        key = torch.cuda.current_device()
+    if key not in _PERSISTENT_ERR:
+        _PERSISTENT_ERR[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
+    return _PERSISTENT_ERR[key]
+
+
 def _note_persistent_error(wsb):
     """fold the launch's error word (first int32 of its workspace: a bounded spin gave up) into a sticky
-    per-device counter, on the stream and without a host sync; `check_persistent_errors` reads it."""
-    key = wsb.device.index
-    if key not in _PERSISTENT_ERR:
-        _PERSISTENT_ERR[key] = torch.zeros(1, device=wsb.device, dtype=torch.int32)
-    _PERSISTENT_ERR[key].add_(wsb[:4].view(torch.int32))
+    per-device counter, on the stream and without a host sync; `check_persistent_errors` reads it, and the
+    optimiser's update kernel reads it on device (a timed-out step never reaches the parameters)."""
+    persistent_error_word(wsb.device).add_(wsb[:4].view(torch.int32))
 
 
 def check_persistent_errors():
@@ -996,7 +1012,8 @@ def sumsq(flat, out):
     L.check(L.load().dssvae_sumsq(L.ptr(flat), flat.numel(), L.ptr(ws), L.ptr(out), L.stream()), "dssvae_sumsq")
 
 
-def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm):
+def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm, skip_flag=None):
     with _Span("adam_kernel", 0.0, 28.0 * p.numel()):
         L.check(L.load().dssvae_adam_step(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), lr, beta1, beta2, eps,
-                                          step, L.ptr(sumsq_t), max_norm, None, L.stream()), "dssvae_adam_step")
+                                          step, L.ptr(sumsq_t), max_norm, None, L.ptr(skip_flag), L.stream()),
+                "dssvae_adam_step")

@@ -41,14 +41,14 @@ def loads_bin(data):
     return _Unpickler(io.BytesIO(data)).load()
 
 
-def dump_bin(obj, path, reference_layout=True):
-    """reference_layout=True writes exactly what the reference's pickle.dump writes (class paths under
-    ``dss_vae.structs``): plain pickle of objects whose classes are temporarily presented under those
-    module paths, so the reference's ``pickle.load`` finds its own classes."""
-    if not reference_layout:
-        with open(path, "wb") as f:
-            pickle.dump(obj, f)
-        return
+import contextlib
+
+
+@contextlib.contextmanager
+def reference_class_paths():
+    """While active, Vocab / VocabEntry / PlainExample present themselves under the reference's module paths
+    (``dss_vae.structs.*``), so that pickle (and torch.save, which pickles non-tensor objects) writes the class
+    paths the reference's own loaders resolve."""
     import sys
     import types
     saved_mod, saved_attr = {}, {}
@@ -64,8 +64,7 @@ def dump_bin(obj, path, reference_layout=True):
             saved_attr[(module, name)] = (getattr(mod, name, None), cls.__module__)
             setattr(mod, name, cls)
             cls.__module__ = module
-        with open(path, "wb") as f:
-            pickle.dump(obj, f)
+        yield
     finally:
         for (module, name), (old, old_module) in saved_attr.items():
             cls = _CLASSES[(module, name)]
@@ -79,6 +78,22 @@ def dump_bin(obj, path, reference_layout=True):
                 setattr(sys.modules[module], name, old)
         for mn in saved_mod:
             sys.modules.pop(mn, None)
+
+
+def dump_bin(obj, path, reference_layout=True):
+    """reference_layout=True writes exactly what the reference's pickle.dump writes (class paths under
+    ``dss_vae.structs``), so the reference's ``pickle.load`` finds its own classes."""
+    with (reference_class_paths() if reference_layout else contextlib.nullcontext()):
+        with open(path, "wb") as f:
+            pickle.dump(obj, f)
+
+
+def save_model_bin(obj, path):
+    """torch.save of {'args', 'vocab', 'state_dict'} with the vocabulary pickled under the reference's class
+    paths: the reference's ``torch.load(model.bin)`` finds ``dss_vae.structs.vocab.Vocab``"""
+    import torch
+    with reference_class_paths():
+        torch.save(obj, path)
 
 
 def load_model_bin(path, map_location="cpu"):

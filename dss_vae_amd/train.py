@@ -135,9 +135,13 @@ class FlatAdam(object):
         self.all_reduce_grads()
         self.sumsq.zero_()
         ops.sumsq(self.grad, self.sumsq)
+        # the update is gated on device by the sticky error word of the persistent GRU launches: a step whose
+        # recurrence gave up waiting (garbage gradients) is dropped, not applied; the host learns of it at its
+        # next ops.check_persistent_errors()
+        err = ops.persistent_error_word(self.flat.device)
         for lo, hi, st in self._live_ranges():
             ops.adam_step(self.flat[lo:hi], self.grad[lo:hi], self.m[lo:hi], self.v[lo:hi], self.lr, self.betas[0],
-                          self.betas[1], self.eps, st, self.sumsq if self.clip > 0.0 else None, self.clip)
+                          self.betas[1], self.eps, st, self.sumsq if self.clip > 0.0 else None, self.clip, err)
         for i in self.fired:
             self.steps[i] += 1
 

@@ -74,6 +74,12 @@ def get_lr_schedule(is_better, model, optimizer, main_args, patience, num_trial,
         if not getattr(main_args, "reset_optimizer", False):
             print("restore parameters of the optimizers", file=sys.stdout)
             optimizer.load_state_dict(torch.load(model_file + ".optim.bin", weights_only=True))
+        else:
+            # the reference builds a fresh Adam here (utils/model_utils.py:80-82): moments and step counts restart
+            print("reset optimizer", file=sys.stdout)
+            optimizer.m.zero_()
+            optimizer.v.zero_()
+            optimizer.steps = [0] * len(optimizer.steps)
         for group in optimizer.param_groups:
             group["lr"] = lr
         patience = 0

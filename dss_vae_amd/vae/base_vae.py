@@ -199,4 +199,5 @@ class BaseVAE(nn.Module):
         if not os.path.exists(path + ".config"):
             with open(path + ".config", "w") as f:
                 f.write("{}".format(self.base_information()))
-        torch.save({"args": self.args, "vocab": self.vocab, "state_dict": self.state_dict()}, path)
+        from ..structs.io import save_model_bin
+        save_model_bin({"args": self.args, "vocab": self.vocab, "state_dict": self.state_dict()}, path)

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc */
+#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -289,13 +289,15 @@ int dssvae_greedy_decode_noalloc(const dssvae_decode_params* params, const float
  * Optimiser over flat fp32 buffers (bin/train.py:124-126, utils/model_utils.py:195):
  * sumsq_out[0] += sum(g^2), added up in a fixed order (block partials in `partials`, then one block): the same
  * bits on every data-parallel replica;  Adam step with bias correction and the clip coefficient
- * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) read on device (no host sync).
+ * min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) read on device (no host sync).  skip_flag (may be NULL): a device
+ * int32; when it is non-zero at execution time the whole update is dropped (the caller points it at the sticky
+ * error word of its persistent GRU launches, so a step whose recurrence timed out never reaches the parameters).
  * ------------------------------------------------------------------------------------------- */
 #define DSSVAE_SUMSQ_PARTIALS 2048 /* floats of caller-owned scratch for dssvae_sumsq */
 int dssvae_sumsq(const float* g, int64_t n, float* partials, float* sumsq_out, void* stream);
 int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, const float* sumsq, float max_norm,
-                     const float* grad_scale_mask, void* stream);
+                     const float* grad_scale_mask, const int32_t* skip_flag, void* stream);
 
 #ifdef __cplusplus
 }

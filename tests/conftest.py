@@ -30,3 +30,17 @@ CASES = ["SyntaxVAE2_tiny", "SyntaxVAE2_mid", "SyntaxVAE_tiny", "SyntaxVAE_mid",
 @pytest.fixture(params=CASES)
 def golden_case(request):
     return request.param, load_golden(request.param)
+
+
+@pytest.fixture(autouse=True)
+def _verify_uniform_upstream_contract(request):
+    """every GPU test runs the fused CE schedule with its contract verified (all rows of a linear_ce call receive
+    the same upstream gradient): a model change that breaks it fails here instead of training on wrong gradients"""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    from dss_vae_amd import ops
+    old = ops.CHECK_UNIFORM_UPSTREAM
+    ops.CHECK_UNIFORM_UPSTREAM = True
+    yield
+    ops.CHECK_UNIFORM_UPSTREAM = old

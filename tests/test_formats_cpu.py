@@ -66,6 +66,10 @@ def test_interchange_with_the_reference_classes(tmp_path):
     import subprocess
     _vocab().save(str(tmp_path / "vocab.bin"))
     Dataset([PlainExample(["a", "b"], ["t"])]).save(str(tmp_path / "train.bin"))
+    from argparse import Namespace
+    from dss_vae_amd.structs.io import save_model_bin
+    save_model_bin({"args": Namespace(a=1), "vocab": _vocab(), "state_dict": {"w": torch.ones(2, 3)}},
+                   str(tmp_path / "model.bin"))
     code = r'''
 import sys, types, pickle
 sys.path.insert(0, "/root/reference")
@@ -79,6 +83,12 @@ d = Dataset.from_bin_file(sys.argv[1] + "/train.bin")
 assert d.examples[0].src == ["a", "b"]
 pickle.dump(v, open(sys.argv[1] + "/ref_vocab.bin", "wb"))
 pickle.dump(d.examples, open(sys.argv[1] + "/ref_train.bin", "wb"))
+# model.bin as BaseVAE.save writes it (a file of this package's own making): the reference's torch.load
+# resolves the vocabulary onto ITS classes
+import torch
+ck = torch.load(sys.argv[1] + "/model.bin", map_location="cpu", weights_only=False)
+assert type(ck["vocab"]).__module__ == "dss_vae.structs.vocab" and ck["vocab"].src["hello"] == 4
+assert ck["args"].a == 1 and float(ck["state_dict"]["w"].sum()) == 6.0
 '''
     env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1")
     subprocess.run([sys.executable, "-c", code, str(tmp_path)], check=True, env=env)
@@ -93,6 +103,12 @@ def test_model_bin_loads_without_executing_anything(tmp_path):
     torch.save({"args": Namespace(a=1), "vocab": _vocab(), "state_dict": {"w": torch.ones(2, 3)}}, path)
     d = load_model_bin(path)
     assert d["args"].a == 1 and d["vocab"].src["hello"] == 4 and torch.equal(d["state_dict"]["w"], torch.ones(2, 3))
+    # ... and as BaseVAE.save writes it: vocabulary under the reference's class paths
+    from dss_vae_amd.structs.io import save_model_bin
+    save_model_bin({"args": Namespace(a=2), "vocab": _vocab(), "state_dict": {"w": torch.ones(2, 3)}}, path)
+    d = load_model_bin(path)
+    assert d["args"].a == 2 and type(d["vocab"]) is Vocab and d["vocab"].src["hello"] == 4
+    assert type(_vocab()).__module__ == "dss_vae_amd.structs.vocab"  # the presentation was undone
 
 
 def test_corpus_bleu_known_answers(tmp_path):

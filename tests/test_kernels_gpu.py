@@ -424,3 +424,19 @@ def test_sumsq_and_adam():
         assert abs(ss.sqrt().item() - gn.item()) / gn.item() < 1e-5
         ops.adam_step(pd, gd, m, v, 5e-4, 0.9, 0.995, 1e-8, step, ss, 5.0)
     close(pd, ref_p, rtol=1e-5, atol=1e-6, what="adam")
+
+
+def test_adam_update_is_dropped_when_the_error_word_is_set():
+    """a step whose persistent recurrence timed out must not reach the parameters: the update kernel reads the
+    sticky error word on device"""
+    from dss_vae_amd import ops
+    n = 4099
+    p, g = rnd(n, seed=1).to(DEV), rnd(n, seed=2).to(DEV)
+    m, v = torch.zeros(n, device=DEV), torch.zeros(n, device=DEV)
+    flag = torch.ones(1, device=DEV, dtype=torch.int32)
+    before = p.clone()
+    ops.adam_step(p, g, m, v, 5e-4, 0.9, 0.995, 1e-8, 1, None, 0.0, flag)
+    assert torch.equal(p, before) and not m.any() and not v.any()
+    flag.zero_()
+    ops.adam_step(p, g, m, v, 5e-4, 0.9, 0.995, 1e-8, 1, None, 0.0, flag)
+    assert not torch.equal(p, before) and m.any()
