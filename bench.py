@@ -169,8 +169,18 @@ def main():
     if world != a.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if a.gpus > 1 and world == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (a.gpus, a.gpus))
+        # plain `python bench.py --gpus N`: start the N ranks as CHILD processes (torch.distributed.run, one per
+        # GPU) before anything here has touched the GPU, pass their output through and exit with their code
+        import socket
+        import subprocess
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(cmd, env=env))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path for the product)"
     local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)

@@ -79,3 +79,40 @@ def test_registry_keys(reference_on_path):
     for key in ("VanillaVAE", "DisentangleVAE", "SyntaxVAE", "SyntaxVAE2"):
         assert key in MODEL_CLS and key in ref
         assert MODEL_CLS[key].__name__ == ref[key].__name__
+
+
+def test_reference_import_paths_resolve_to_this_package():
+    """dss_vae_amd.compat.install(): a reference-side caller's import lines work unchanged (in a child process:
+    the aliases must not leak into the tests that import the real reference)"""
+    import subprocess
+    code = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+import dss_vae_amd.compat as compat
+names = compat.install()
+from dss_vae.models import MODEL_CLS, init_create_model
+from dss_vae.vae.syntax_vae import SyntaxVAE
+from dss_vae.vae.enhance_syntax_vae import EnhanceSyntaxVAE
+from dss_vae.vae.vanilla_vae import VanillaVAE
+from dss_vae.vae.disentangle_vae import DisentangleVAE
+from dss_vae.encoder import RNNEncoder
+from dss_vae.decoder import RNNDecoder
+from dss_vae.networks.bridger import MLPBridger
+from dss_vae.networks.embeddings import Embeddings
+from dss_vae.structs.vocab import Vocab, VocabEntry
+from dss_vae.structs.dataset import Dataset, PlainExample
+from dss_vae.utils.nn_funcs import to_input_variable, unk_replace, id2word
+from dss_vae.utils.model_utils import build_model, get_lr_schedule
+from dss_vae.metrics.syntax_vae_evaluator import SyntaxVaeEvaluator
+import dss_vae_amd.models, dss_vae_amd.vae.syntax_vae, dss_vae_amd.structs.vocab
+assert MODEL_CLS is dss_vae_amd.models.MODEL_CLS
+assert MODEL_CLS["SyntaxVAE"] is SyntaxVAE is dss_vae_amd.vae.syntax_vae.SyntaxVAE
+assert MODEL_CLS["SyntaxVAE2"] is EnhanceSyntaxVAE and MODEL_CLS["VanillaVAE"] is VanillaVAE
+assert MODEL_CLS["DisentangleVAE"] is DisentangleVAE
+assert Vocab is dss_vae_amd.structs.vocab.Vocab
+assert "dss_vae.models" in names and "dss_vae.vae.base_vae" in names
+compat.uninstall()
+assert "dss_vae" not in sys.modules
+'''
+    subprocess.run([sys.executable, "-c", code, ROOT], check=True,
+                   env=dict(os.environ, PYTHONDONTWRITEBYTECODE="1"))
