@@ -36,6 +36,11 @@ struct OpA {
     const float* p1; int64_t ld1; int K1;
     const float* p2; int64_t ld2;
     const int64_t* rows;
+    // XF stagers only: the operand in memory is a LOGITS slab [slab rows, vocabulary columns]; what enters the
+    // LDS image is the softmax part of dlogits, coef * exp(logit - lse) = exp2(logit * log2(e) - l2), computed
+    // while the tile is staged from ONE float per slab row: l2 = (lse - ln coef) * log2(e)  (+inf where coef = 0).
+    // The one-hot part of dlogits is a rank-one-per-row correction of the products (ce_onehot_fixup_kernel).
+    const float* xf;
 };
 struct OpB {
     const float* p; int64_t ld;
@@ -54,8 +59,9 @@ template <> struct VecT<4> { typedef float4 T; static __device__ __forceinline__
 template <> struct VecT<2> { typedef float2 T; static __device__ __forceinline__ T zero() { return make_float2(0.f, 0.f); } };
 template <> struct VecT<1> { typedef float T; static __device__ __forceinline__ T zero() { return 0.f; } };
 
-template <bool TRANS, int VW, int R>
+template <bool TRANS, int VW, int R, bool XF = false>
 struct Stager {
+    static_assert(!XF || VW == 4, "the dlogits transform is written for 16-byte granules");
     static constexpr bool VEC = VW > 1;
     typedef typename VecT<VW>::T V;
     static constexpr int NV = R * BK / (NTHREADS * (VEC ? VW : 4));  // granules per thread (VEC)
@@ -65,6 +71,8 @@ struct Stager {
     static constexpr int RPS = NTHREADS / BK;    // rows per pass (scalar)
     V v[VEC ? NV : 1];
     float s[VEC ? 1 : NS];
+    float ri[XF ? NV : 1];    // l2 of the slab rows of the staged granules (XF)
+    const float* xf;
     const float* b1[(!TRANS && VEC) ? NV : 1];
     const float* b2[(!TRANS && VEC) ? NV : 1];
     const float* p1; const float* p2; const int64_t* rows;
@@ -73,18 +81,31 @@ struct Stager {
     unsigned okmask;  // which staged registers hold in-range k (the k tail is zeroed when written to LDS)
 
     __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int K1_, const float* p2_, int64_t ld2_,
-                                         const int64_t* rows_, int Rtot_, int r0_, int K_) {
+                                         const int64_t* rows_, int Rtot_, int r0_, int K_, const float* xf_ = nullptr) {
+        xf = xf_;
         p1 = p1_; ld1 = ld1_; K1 = K1_; p2 = p2_ ? p2_ : p1_; ld2 = p2_ ? ld2_ : ld1_; rows = rows_;
         Rtot = Rtot_; r0 = r0_; K = K_;
         if (!TRANS && VEC) {
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int r = min(r0 + (int)(threadIdx.x / TPR) + RPP * i, Rtot - 1);
-                const int64_t ri = rows ? rows[r] : (int64_t)r;
-                b1[i] = p1 + ri * ld1;
-                b2[i] = p2 + ri * ld2;
+                const int64_t ri_ = rows ? rows[r] : (int64_t)r;
+                b1[i] = p1 + ri_ * ld1;
+                b2[i] = p2 + ri_ * ld2;
+                if (XF) ri[i] = xf[r];   // the slab rows of this thread's granules never change
             }
         }
+    }
+
+    // softmax part of dlogits for one granule of a slab row: two VALU instructions per element (v_fma, v_exp)
+    static __device__ __forceinline__ float4 dlogits(float4 x, float l2) {
+        constexpr float LOG2E = 1.4426950408889634f;
+        float4 o;
+        o.x = __builtin_amdgcn_exp2f(__builtin_fmaf(x.x, LOG2E, -l2));
+        o.y = __builtin_amdgcn_exp2f(__builtin_fmaf(x.y, LOG2E, -l2));
+        o.z = __builtin_amdgcn_exp2f(__builtin_fmaf(x.z, LOG2E, -l2));
+        o.w = __builtin_amdgcn_exp2f(__builtin_fmaf(x.w, LOG2E, -l2));
+        return o;
     }
 
     // The tile's loads and LDS stores are cut into 4 parts so that the mainloop can spread them between
@@ -137,6 +158,7 @@ struct Stager {
                         const bool ok = k < K;
                         okmask |= ok ? (1u << i) : 0u;
                         v[i] = *reinterpret_cast<const V*>(p1 + (int64_t)(ok ? k : 0) * ld1 + rv);
+                        if (XF) ri[i] = xf[ok ? k : 0];
                     }
             } else {
                 constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
@@ -159,14 +181,25 @@ struct Stager {
         for (int part = 0; part < 4; ++part) load_part(part);
     }
 
+    // XF: the staged granules of one part become dlogits in place (before store_part writes them to LDS)
+    __device__ __forceinline__ void xform_part(int part) {
+        if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part)) v[i] = dlogits(v[i], ri[i]);
+        }
+    }
+
     __device__ __forceinline__ void store_part(float* img, int part) const {
         if (!TRANS) {
             if (VEC) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (in_part(i, part))
+                    if (in_part(i, part)) {
+                        const V val = v[i];
                         *reinterpret_cast<V*>(img + ((threadIdx.x / TPR) + RPP * i) * LDK + VW * (threadIdx.x % TPR)) =
-                            okmask ? v[i] : VecT<VW>::zero();
+                            okmask ? val : VecT<VW>::zero();
+                    }
             } else {
 #pragma unroll
                 for (int e = 0; e < NS; ++e)
@@ -179,9 +212,11 @@ struct Stager {
                 constexpr int KSTEP = NTHREADS / TPK;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
-                    if (in_part(i, part))
+                    if (in_part(i, part)) {
+                        const V val = v[i];
                         *reinterpret_cast<V*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + VW * (threadIdx.x % TPK)) =
-                            ((okmask >> i) & 1u) ? v[i] : VecT<VW>::zero();
+                            ((okmask >> i) & 1u) ? val : VecT<VW>::zero();
+                    }
             } else {
                 constexpr int KSTEP = NTHREADS / R;
 #pragma unroll
@@ -212,7 +247,7 @@ __device__ __forceinline__ void read_frag(float (&f)[4], const float* img, int r
 }
 
 // ---- one (64*WM) x (64*WN) output tile over k-tiles [kt0, kt1) -----------------------------------
-template <bool TA, bool TB, int VW, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
 __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M, int N, int K, int m0, int n0,
                                               int kt0, int kt1, float* lds, f32x16 (&acc)[WM][WN]) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -229,9 +264,9 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Stager<TA, VW, BM> sa;
+    Stager<TA, VW, BM, XF> sa;
     Stager<TB, VW, BN> sb;
-    sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K);
+    sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K, XF ? a.xf : nullptr);
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
     // Rotated software pipeline.  Per k-tile: NG groups of 8 k (4 MFMAs per 32x32 tile each); the
@@ -248,6 +283,8 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
     constexpr int G_STORE = 0, G_LOAD = 1;  // the loads overwrite the registers (and okmask) the stores read
     sa.load(kt0 * BK);
     sb.load(kt0 * BK);
+#pragma unroll
+    for (int part = 0; part < 4; ++part) sa.xform_part(part);
     sa.store(As);
     sb.store(Bs);
     {
@@ -285,8 +322,18 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
                     for (int j = 0; j < WN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
                 if (g == G_STORE) {
+                    sa.xform_part(jj);
                     sa.store_part(An, jj);
                     sb.store_part(Bn, jj);
+                    if constexpr (XF) {
+                        // one granule's transform (4 x {v_fma, v_exp}) rides between this sub-step's MFMAs instead of
+                        // queueing behind the last one: an MFMA keeps the matrix pipe busy for 64 cycles
+#pragma unroll
+                        for (int q = 0; q < WM * WN; ++q) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, (8 + WM * WN - 1) / (WM * WN), 0);  // VALU
+                        }
+                    }
                 }
                 if (g == G_LOAD) {
                     if (jj == 0) { sa.begin_load(k2); sb.begin_load(k2); }
@@ -373,7 +420,7 @@ __device__ __forceinline__ void tile_to_global(const f32x16 (&acc)[WM][WN], floa
 }
 
 // ---- STORE ---------------------------------------------------------------------------------------
-template <bool TA, bool TB, int VW, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
 __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
                                                 const float* __restrict__ bias, int M, int N, int K, float alpha,
                                                 float beta, int tiles_n, int ksplit, int kt_per_split, int cvec,
@@ -385,7 +432,7 @@ __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, floa
     const int kt0 = ks * kt_per_split, kt1 = min(nk, kt0 + kt_per_split);
     if (kt0 >= kt1) return;
     f32x16 acc[WM][WN];
-    tile_mainloop<TA, TB, VW, WM, WN>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
+    tile_mainloop<TA, TB, VW, WM, WN, XF>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
     if (ksplit > 1) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
@@ -415,15 +462,49 @@ __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, floa
     tile_to_global<WM, WN>(acc, lds, C, ldc, m0, n0, M, N, beta, cvec != 0);
 }
 
-template <bool TA, bool TB, int VW, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
 __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, float* __restrict__ C, int64_t ldc,
                                                                const float* __restrict__ bias, int M, int N, int K,
                                                                float alpha, float beta, int tiles_n, int ntiles,
                                                                int ksplit, int kt_per_split, int cvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int wid = xcd_remap(blockIdx.x, ntiles * ksplit);
-    store_tile_body<TA, TB, VW, WM, WN>(a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ksplit, kt_per_split, cvec,
-                                         wid, lds);
+    store_tile_body<TA, TB, VW, WM, WN, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, tiles_n, ksplit, kt_per_split,
+                                             cvec, wid, lds);
+}
+
+// l2 of one slab row for the XF stagers: coef * exp(x - lse) = exp2(x * log2(e) - l2)
+__global__ void ce_rowinfo_kernel(const float* __restrict__ lse, const float* __restrict__ coef, int M,
+                                  float* __restrict__ out) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    const float c = coef[m];
+    out[m] = c > 0.f ? (lse[m] - __logf(c)) * 1.4426950408889634f : __builtin_inff();
+}
+
+// One-hot part of dlogits, dL[m, target[m]] -= w, as corrections of the two products (one wave per slab row):
+//   dX[m, :]        -= w * Wp[target[m], :]      (Wp: the weight panel of the dgrad)
+//   dW[target[m], :] -= w * Xc[m, :]             (Xc: the wgrad's right operand, ones column included; atomic)
+__global__ void ce_onehot_fixup_kernel(const int64_t* __restrict__ target, int64_t ignore, const float* __restrict__ g,
+                                       int rows, const float* __restrict__ Wp, int64_t ldw, int Kx,
+                                       float* __restrict__ dX, int64_t lddx, const float* __restrict__ Xc, int64_t ldxc,
+                                       int Kw, float* __restrict__ dW, int64_t lddw) {
+    const int m = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (m >= rows) return;
+    const int64_t t = target[m];
+    if (t == ignore) return;
+    const float w = g ? g[m] : 1.f;
+    const int lane = threadIdx.x & 63;
+    if (dX) {
+        const float* src = Wp + t * ldw;
+        float* dst = dX + (int64_t)m * lddx;
+        for (int k = lane; k < Kx; k += 64) dst[k] -= w * src[k];
+    }
+    if (dW) {
+        const float* src = Xc + (int64_t)m * ldxc;
+        float* dst = dW + t * lddw;
+        for (int k = lane; k < Kw; k += 64) unsafeAtomicAdd(dst + k, -w * src[k]);
+    }
 }
 
 // ---- grouped STORE: up to DSSVAE_GEMM_MAX_GROUP independent products of one layout in ONE launch ----
@@ -731,7 +812,7 @@ int operand_vw(const float* p, int64_t ld, bool trans, int rows, int K) {
 
 OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, bool* vec) {
     OpA a;
-    a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr;
+    a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr; a.xf = nullptr;
     *vec = vec_ok(Xh, ldh) && (Ke == 0 || vec_ok(Xe, lde)) && (Kh % 4 == 0) && (Ke % 4 == 0);
     return a;
 }
@@ -779,7 +860,7 @@ StorePlan plan_store(int M, int N, int K, int bn, bool may_split) {
     return best;
 }
 
-template <bool TA, bool TB, int VW, int WM, int WN>
+template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
 int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                  float alpha, float beta, int ksplit_req, hipStream_t s) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
@@ -796,7 +877,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
         if (e != DSSVAE_OK) return e;
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
-    auto kern = gemm_store_kernel<TA, TB, VW, WM, WN>;
+    auto kern = gemm_store_kernel<TA, TB, VW, WM, WN, XF>;
     allow_lds(kern, lds_bytes);
     const int cvec = aligned16(C) && (ldc % 4) == 0 && (N % 4) == 0;
     hipLaunchKernelGGL(kern, dim3(ntiles * ksplit), dim3(NTHREADS), lds_bytes, s, a, b, C, ldc, bias, M, N, K, alpha,
@@ -805,7 +886,7 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     return DSSVAE_OK;
 }
 
-template <bool TA, bool TB, int VW>
+template <bool TA, bool TB, int VW, bool XF = false>
 int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                       float alpha, float beta, int ksplit, hipStream_t s) {
     // tile width (128x128 or 128x64) by the cost model above
@@ -814,8 +895,8 @@ int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const f
     const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width
     if (force == 64) narrow = true;
     if (force == 128) narrow = false;
-    if (narrow) return launch_store<TA, TB, VW, 2, 1>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
-    return launch_store<TA, TB, VW, 2, 2>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
+    if (narrow) return launch_store<TA, TB, VW, 2, 1, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
+    return launch_store<TA, TB, VW, 2, 2, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
 }
 
 }  // namespace
@@ -836,7 +917,7 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
     if ((trans_a ? lda < M : lda < K) || (trans_b ? ldb < N : ldb < K)) return DSSVAE_EINVAL;
     if (M == 0 || N == 0) return DSSVAE_OK;
     OpA a;
-    a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows;
+    a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows; a.xf = nullptr;
     OpB b;
     b.p = B; b.ld = ldb;
     // widest granule both operands allow: every granule is aligned and entirely in or out of range
@@ -907,7 +988,7 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
         if (!x.A || !x.B || !x.C || x.M <= 0 || x.N <= 0 || x.K <= 0 || x.ldc < x.N) return DSSVAE_EINVAL;
         if ((trans_a ? x.lda < x.M : x.lda < x.K) || (trans_b ? x.ldb < x.N : x.ldb < x.K)) return DSSVAE_EINVAL;
         GroupProblem& q = g.p[i];
-        q.a.p1 = x.A; q.a.ld1 = x.lda; q.a.K1 = x.K; q.a.p2 = nullptr; q.a.ld2 = 0; q.a.rows = nullptr;
+        q.a.p1 = x.A; q.a.ld1 = x.lda; q.a.K1 = x.K; q.a.p2 = nullptr; q.a.ld2 = 0; q.a.rows = nullptr; q.a.xf = nullptr;
         q.b.p = x.B; q.b.ld = x.ldb;
         q.C = x.C; q.ldc = x.ldc; q.bias = x.bias;
         q.M = x.M; q.N = x.N; q.K = x.K;
@@ -1052,4 +1133,49 @@ extern "C" int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* o
     hipLaunchKernelGGL(colsum_kernel, dim3(col_blocks, row_blocks), dim3(256), 0, s, X, ldx, M, N, out, rpb);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
+}
+
+extern "C" int dssvae_ce_rowinfo(const float* lse, const float* coef, int M, float* rowinfo, void* stream) {
+    if (!lse || !coef || !rowinfo || M <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(ce_rowinfo_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, lse, coef, M,
+                       rowinfo);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_ce_onehot_fixup(const int64_t* target, int64_t ignore_index, const float* g, int rows,
+                                      const float* W_panel, int64_t ldw, int Kx, float* dX, int64_t lddx,
+                                      const float* Xc, int64_t ldxc, int Kw, float* dW, int64_t lddw, void* stream) {
+    if (!target || rows <= 0 || (dX && (!W_panel || Kx <= 0 || lddx < Kx)) || (dW && (!Xc || Kw <= 0 || lddw < Kw)))
+        return DSSVAE_EINVAL;
+    if (!dX && !dW) return DSSVAE_OK;
+    hipLaunchKernelGGL(ce_onehot_fixup_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, target,
+                       ignore_index, g, rows, W_panel, ldw, Kx, dX, lddx, Xc, ldxc, Kw, dW, lddw);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int rows, int cols, const float* rowinfo,
+                                       int trans_a, const float* B, int64_t ldb, float* C, int64_t ldc, int N,
+                                       float beta, void* stream) {
+    if (!logits || !rowinfo || !B || !C || rows <= 0 || cols <= 0 || N <= 0 || ldl < cols || ldb < N || ldc < N)
+        return DSSVAE_EINVAL;
+    if (beta != 0.f && beta != 1.f) return DSSVAE_EINVAL;
+    // 16-byte granules everywhere: the caller falls back to dssvae_softmax_grad_inplace + dssvae_gemm_f32 otherwise
+    if (!aligned16(logits) || (ldl % 4) != 0 || (cols % 4) != 0 || !aligned16(B) ||
+        (ldb % 4) != 0 || (N % 4) != 0)
+        return DSSVAE_ETOOBIG;
+    OpA a;
+    a.p1 = logits; a.ld1 = ldl; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr;
+    a.xf = rowinfo;
+    OpB b;
+    b.p = B; b.ld = ldb;
+    hipStream_t s = (hipStream_t)stream;
+    if (!trans_a) {  // C[rows, N] = dlogits . B       (contraction over the vocabulary)
+        a.K1 = cols;
+        return launch_store_tile<false, true, 4, true>(a, b, C, ldc, nullptr, rows, N, cols, 1.f, beta, 0, s);
+    }
+    // C[cols, N] = dlogits^T . B                   (contraction over the slab rows)
+    a.K1 = rows;
+    return launch_store_tile<true, true, 4, true>(a, b, C, ldc, nullptr, cols, N, rows, 1.f, beta, 0, s);
 }

@@ -33,12 +33,14 @@ constexpr int UU = 16;   // hidden units per workgroup (M of the 16x16x4 MFMA)
 constexpr int CH = 8;    // exchange slices fetched per register chunk
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 constexpr int CNT_STRIDE = 32;  // one 128-B line per counter
+constexpr int LDS_BUDGET = 150 * 1024;  // W_hh slice of a workgroup
+constexpr int MAX_WG_PER_CU = 4;
 
 typedef unsigned int u32x4v __attribute__((__vector_size__(16)));
 
 struct FwdDev {
     dssvae_gru_fwd_inst in;
-    int wg_begin, n_slices, n_bblocks;
+    int wg_begin, n_slices, n_bblocks, rows;  // rows: batch rows per cell of this instance (16, 32, 64 or 128)
     unsigned* counters;
     float* hx;  // [2][n_bblocks][n_slices][64][16]
 };
@@ -49,7 +51,7 @@ struct FwdArgs {
 };
 struct BwdDev {
     dssvae_gru_bwd_inst in;
-    int wg_begin, n_slices, n_bblocks;
+    int wg_begin, n_slices, n_bblocks, rows;
     unsigned* counters;
     float* gx;  // [2][n_bblocks][n_slices][3][64][16]
 };
@@ -135,7 +137,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, in
 // SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
 template <int WV>
 __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
-    constexpr int BB = 16 * WV, NTHR = 64 * WV, BLK = BB * UU;
+    constexpr int NTHR = 64 * WV;
     // Ws[g][slice s][c][kq][j] = whh[(g*H + u0 + j)*H + 16 s + 4 kq + c]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -145,6 +147,9 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
     const int H = in.H, T = in.T, B = in.B, NS = d.n_slices;
+    // cells of this instance hold BB batch rows (<= 16 WV): waves beyond BB / 16 only help to fill LDS
+    const int BB = d.rows, WVI = BB >> 4, BLK = BB * UU;
+    const int Tt = in.T_total > 0 ? in.T_total : T;   // row stride of the [B, T_total, .] histories
     const int u0 = slice * UU;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -152,7 +157,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;                       // first of this lane's 4 units
     const int n_ok = max(0, min(4, H - ub));          // how many of them exist
-    unsigned* cnt = d.counters + ((size_t)bblock * WV + wave) * CNT_STRIDE;  // this wave's row group
+    unsigned* cnt = d.counters + ((size_t)bblock * WVI + wave) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
     const int gate_stride = NS * 256;
 
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int c = 0; c < 4; ++c) bh[g][c] = (c < n_ok) ? in.bhh[g * H + ub + c] : 0.f;
-    const int len = (in.lengths && row_ok) ? in.lengths[b] : T;
+    const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
 
     // exchange buffers of this batch block: [2][NS][64][16]; this lane's piece of its own block
     const unsigned half_bytes = (unsigned)NS * BLK * 4u;
@@ -180,6 +185,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const int own = slice * BLK * 4;
 
     __syncthreads();  // the slice is in LDS for every wave; from here on the waves run free
+    if (wave >= WVI) return;
     // state 0 into the exchange buffer (pad units and pad rows are zero and stay zero)
     float hcur[4] = {0.f, 0.f, 0.f, 0.f};
     if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
@@ -188,10 +194,11 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 
     const float* Wl = Ws + kq * 16 + j;
     for (int step = 0; step < T; ++step) {
-        const int t = in.reverse ? T - 1 - step : step;
+        const int gs = in.t0 + step;  // step of the whole recurrence (this launch runs steps t0 .. t0 + T - 1)
+        const int t = in.reverse ? Tt - 1 - gs : gs;
         const __amdgpu_buffer_rsrc_t rin = (step & 1) ? rs1 : rs0, rout = (step & 1) ? rs0 : rs1;
         // the x-projection gates of this step do not depend on the hand-off: fetch them first
-        const size_t bt = (size_t)(row_ok ? b : 0) * T + t;
+        const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
         const float* xp = in.xproj + bt * in.ldx;
         float xr[4], xz[4], xn[4];
         const bool vec_x = vec_h && (in.ldx % 4) == 0;
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 // SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
 template <int WV>
 __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
-    constexpr int BB = 16 * WV, NTHR = 64 * WV, BLK = BB * UU;
+    constexpr int NTHR = 64 * WV;
     // chunk q = 3*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -268,6 +275,8 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
     const int H = in.H, T = in.T, B = in.B, K = 3 * H, NS = d.n_slices, NQ = 3 * NS;
+    const int BB = d.rows, WVI = BB >> 4, BLK = BB * UU;
+    const int Tt = in.T_total > 0 ? in.T_total : T;
     const int u0 = slice * UU;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int j = lane & 15, kq = lane >> 4;
@@ -275,7 +284,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;
     const int n_ok = max(0, min(4, H - ub));
-    unsigned* cnt = d.counters + ((size_t)bblock * WV + wave) * CNT_STRIDE;  // this wave's row group
+    unsigned* cnt = d.counters + ((size_t)bblock * WVI + wave) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
 
     for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         const float w = (cu < H && u < H) ? in.whh[(size_t)(g * H + cu) * H + u] : 0.f;
         Ws[q * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + i] = w;
     }
-    const int len = (in.lengths && row_ok) ? in.lengths[b] : T;
+    const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
     float dh[4] = {0.f, 0.f, 0.f, 0.f};
     if (row_ok && in.dh_last) load4(dh, in.dh_last + (size_t)b * H + ub, vec_h, n_ok);
 
@@ -297,20 +306,21 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;
     const int own = slice * 3 * BLK * 4;
     __syncthreads();
+    if (wave >= WVI) return;
 
     const float* Wl = Ws + kq * 16 + j;
     // bias gradients (column sums of dgx / dgh over batch and time) ride along in registers
     float sb_r[4] = {0.f, 0.f, 0.f, 0.f}, sb_z[4] = {0.f, 0.f, 0.f, 0.f}, sb_n[4] = {0.f, 0.f, 0.f, 0.f},
           sb_m[4] = {0.f, 0.f, 0.f, 0.f};
     for (int step = 0; step < T; ++step) {
-        // backward walks the forward order in reverse
-        const int fstep = T - 1 - step;
-        const int t = in.reverse ? T - 1 - fstep : fstep;
+        // backward walks the forward order in reverse: forward steps t0 + T - 1 down to t0 of the recurrence
+        const int fstep = in.t0 + T - 1 - step;
+        const int t = in.reverse ? Tt - 1 - fstep : fstep;
         const __amdgpu_buffer_rsrc_t rcur = (step & 1) ? rs1 : rs0;
         float dhz[4] = {0.f, 0.f, 0.f, 0.f};
         float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dgz[4] = {0.f, 0.f, 0.f, 0.f}, dgn[4] = {0.f, 0.f, 0.f, 0.f},
               dgm[4] = {0.f, 0.f, 0.f, 0.f};
-        const size_t bt = (size_t)(row_ok ? b : 0) * T + t;
+        const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
         if (row_ok && n_ok > 0) {
             const bool live = t < len;
             if (live) {
@@ -417,7 +427,8 @@ struct Layout {
 
 inline int round16(int x) { return (x + 15) & ~15; }
 
-// exchange buffers are sized for the backward pass (3 gate blocks per slice); forward uses a third
+// exchange buffers are sized for the backward pass (3 gate blocks per slice); forward uses a third.  The sizes
+// hold for every cell height (16 .. 128 rows): counters are per 16-row group, buffers per 128-row-padded batch.
 Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     Layout L;
     size_t off = 256;  // error word + padding
@@ -446,19 +457,74 @@ int cu_count() {
     return cus;
 }
 
-// waves per workgroup of a launch: 4 (one workgroup per 64 rows x 16 units) when every cell gets its own
-// CU, else 8 (128 rows per workgroup); 0 = does not fit either way.  DSSVAE_GRU_WAVES=8 forces 8 (tests).
-int pick_waves(int n_inst, const int32_t* B, const int32_t* H) {
-    int wg4 = 0, wg8 = 0;
-    for (int i = 0; i < n_inst; ++i) {
-        const int ns = round16(H[i]) / UU;
-        wg4 += ((B[i] + 63) / 64) * ns;
-        wg8 += ((B[i] + 127) / 128) * ns;
+const void* fwd_kernel(int wv) {
+    switch (wv) {
+        case 1: return reinterpret_cast<const void*>(gru_fwd_kernel<1>);
+        case 2: return reinterpret_cast<const void*>(gru_fwd_kernel<2>);
+        case 4: return reinterpret_cast<const void*>(gru_fwd_kernel<4>);
+        default: return reinterpret_cast<const void*>(gru_fwd_kernel<8>);
     }
+}
+const void* bwd_kernel(int wv) {
+    switch (wv) {
+        case 1: return reinterpret_cast<const void*>(gru_bwd_kernel<1>);
+        case 2: return reinterpret_cast<const void*>(gru_bwd_kernel<2>);
+        case 4: return reinterpret_cast<const void*>(gru_bwd_kernel<4>);
+        default: return reinterpret_cast<const void*>(gru_bwd_kernel<8>);
+    }
+}
+
+inline int lds_bytes_for(int H_max) { return 3 * (round16(H_max) / UU) * 256 * (int)sizeof(float); }
+
+// How many workgroups of a persistent launch the chip holds AT ONCE: the runtime's occupancy answer for this
+// kernel, block size and LDS slice, times the CU count.  Every workgroup of a launch must be resident (the step
+// hand-off spins on peers), so this is the bound on the grid -- not the CU count: an H = 300 slice is 57 KB of
+// the CU's 160 KB of LDS, two such workgroups share a CU.  0 = the slice does not fit at all.
+int resident_workgroups(bool backward, int wv, int lds_bytes) {
+    if (lds_bytes > LDS_BUDGET || lds_bytes <= 0) return 0;
+    // the answer depends on (kernel, block size, LDS slice) only: asked once (lds is a multiple of 3 KB)
+    static int cache[2][4][LDS_BUDGET / 3072 + 1];  // 0 = not asked yet, -1 = asked: none
+    const int wi = wv == 1 ? 0 : wv == 2 ? 1 : wv == 4 ? 2 : 3;
+    int& c = cache[backward ? 1 : 0][wi][lds_bytes / 3072];
+    if (c == 0) {
+        const void* k = backward ? bwd_kernel(wv) : fwd_kernel(wv);
+        int per_cu = 0;
+        // the attribute is per kernel, not per launch: raise it to the budget once, whatever this launch needs
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * wv, (size_t)lds_bytes) != hipSuccess)
+            per_cu = 0;
+        if (per_cu > MAX_WG_PER_CU) per_cu = MAX_WG_PER_CU;
+        c = per_cu > 0 ? per_cu * cu_count() : -1;
+    }
+    return c > 0 ? c : 0;
+}
+
+// cell height (batch rows per workgroup) of every instance and the launch's waves per workgroup.  An instance
+// may ask for its own height (inst.rows in {16, 32, 64, 128}); 0 = the library's choice for the whole launch:
+// 64 rows when the grid is resident that way, else 128.  DSSVAE_GRU_WAVES=8 forces 128 (tests).
+// -> waves per workgroup (1, 2, 4, 8), 0 = not resident either way, -1 = bad rows value
+int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want, int* rows_out) {
+    int max_h = 0;
+    bool any_auto = false;
+    for (int i = 0; i < n_inst; ++i) {
+        if (H[i] > max_h) max_h = H[i];
+        if (want[i] == 0) any_auto = true;
+        else if (want[i] != 16 && want[i] != 32 && want[i] != 64 && want[i] != 128) return -1;
+    }
+    const int lds = lds_bytes_for(max_h);
     const char* f = getenv("DSSVAE_GRU_WAVES");
-    if (f && atoi(f) == 8 && wg8 <= cu_count()) return 8;
-    if (wg4 <= cu_count()) return 4;
-    if (wg8 <= cu_count()) return 8;
+    const bool force8 = f && atoi(f) == 8;
+    const int cand[2] = {force8 ? 128 : 64, 128};
+    for (int c = 0; c < (any_auto ? 2 : 1); ++c) {
+        int wg = 0, max_rows = 16;
+        for (int i = 0; i < n_inst; ++i) {
+            rows_out[i] = want[i] ? want[i] : cand[c];
+            wg += ((B[i] + rows_out[i] - 1) / rows_out[i]) * (round16(H[i]) / UU);
+            if (rows_out[i] > max_rows) max_rows = rows_out[i];
+        }
+        const int wv = max_rows / 16;
+        if (wg <= resident_workgroups(backward, wv, lds)) return wv;
+    }
     return 0;
 }
 
@@ -471,47 +537,54 @@ extern "C" int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host,
     return (int64_t)plan(n_inst, B_host, H_host).total_bytes;
 }
 
+extern "C" int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host) {
+    if (!n_host || H_max <= 0 || (rows_max != 16 && rows_max != 32 && rows_max != 64 && rows_max != 128))
+        return DSSVAE_EINVAL;
+    *n_host = resident_workgroups(backward != 0, rows_max / 16, lds_bytes_for(H_max));
+    return DSSVAE_OK;
+}
+
 extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void* workspace, int64_t workspace_bytes,
                               void* stream) {
     if (!inst || n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !workspace) return DSSVAE_EINVAL;
-    int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST];
+    int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST], want[DSSVAE_GRU_MAX_INST];
     for (int i = 0; i < n_inst; ++i) {
         const dssvae_gru_fwd_inst& x = inst[i];
         if (!x.xproj || !x.whh || !x.bhh || !x.out || x.B <= 0 || x.T <= 0 || x.H <= 0 || x.ldx < 3 * x.H ||
-            x.ldo < x.H)
+            x.ldo < x.H || x.t0 < 0 || (x.T_total > 0 && x.t0 + x.T > x.T_total) || (x.T_total <= 0 && x.t0 != 0))
             return DSSVAE_EINVAL;
-        Bs[i] = x.B; Hs[i] = x.H;
+        Bs[i] = x.B; Hs[i] = x.H; want[i] = x.rows;
     }
     const Layout L = plan(n_inst, Bs, Hs);
     if ((int64_t)L.total_bytes > workspace_bytes || !aligned16(workspace)) return DSSVAE_EINVAL;
     FwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
-    const int wv = pick_waves(n_inst, Bs, Hs);
+    int rows[DSSVAE_GRU_MAX_INST];
+    const int wv = pick_rows(false, n_inst, Bs, Hs, want, rows);
+    if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
-    const int bbk = 16 * wv;
-    int wg = 0, max_ns = 0;
+    int wg = 0, max_h = 0;
     for (int i = 0; i < n_inst; ++i) {
         FwdDev& d = args.inst[i];
         d.in = inst[i];
+        d.rows = rows[i];
         d.n_slices = round16(inst[i].H) / UU;
-        d.n_bblocks = (inst[i].B + bbk - 1) / bbk;
+        d.n_bblocks = (inst[i].B + rows[i] - 1) / rows[i];
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
         d.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
-        if (d.n_slices > max_ns) max_ns = d.n_slices;
+        if (inst[i].H > max_h) max_h = inst[i].H;
     }
-    const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
-    if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
+    const int lds_bytes = lds_bytes_for(max_h);
     hipStream_t s = (hipStream_t)stream;
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
-    auto kern = wv == 4 ? gru_fwd_kernel<4> : gru_fwd_kernel<8>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wv), lds_bytes, s, args);
+    void* kargs[] = {&args};
+    const hipError_t le = hipLaunchKernel(fwd_kernel(wv), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
+    if (le != hipSuccess) return (int)le;
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -519,43 +592,44 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
 extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void* workspace, int64_t workspace_bytes,
                               void* stream) {
     if (!inst || n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !workspace) return DSSVAE_EINVAL;
-    int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST];
+    int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST], want[DSSVAE_GRU_MAX_INST];
     for (int i = 0; i < n_inst; ++i) {
         const dssvae_gru_bwd_inst& x = inst[i];
-        if (!x.whh || !x.gates || !x.dgx || !x.dgh || x.B <= 0 || x.T <= 0 || x.H <= 0 || (x.dout && x.ldd < x.H))
+        if (!x.whh || !x.gates || !x.dgx || !x.dgh || x.B <= 0 || x.T <= 0 || x.H <= 0 || (x.dout && x.ldd < x.H) ||
+            x.t0 < 0 || (x.T_total > 0 && x.t0 + x.T > x.T_total) || (x.T_total <= 0 && x.t0 != 0))
             return DSSVAE_EINVAL;
-        Bs[i] = x.B; Hs[i] = x.H;
+        Bs[i] = x.B; Hs[i] = x.H; want[i] = x.rows;
     }
     const Layout L = plan(n_inst, Bs, Hs);
     if ((int64_t)L.total_bytes > workspace_bytes || !aligned16(workspace)) return DSSVAE_EINVAL;
     BwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
-    const int wv = pick_waves(n_inst, Bs, Hs);
+    int rows[DSSVAE_GRU_MAX_INST];
+    const int wv = pick_rows(true, n_inst, Bs, Hs, want, rows);
+    if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
-    const int bbk = 16 * wv;
-    int wg = 0, max_ns = 0;
+    int wg = 0, max_h = 0;
     for (int i = 0; i < n_inst; ++i) {
         BwdDev& d = args.inst[i];
         d.in = inst[i];
+        d.rows = rows[i];
         d.n_slices = round16(inst[i].H) / UU;
-        d.n_bblocks = (inst[i].B + bbk - 1) / bbk;
+        d.n_bblocks = (inst[i].B + rows[i] - 1) / rows[i];
         d.wg_begin = wg;
         wg += d.n_slices * d.n_bblocks;
         d.counters = reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + L.cnt_off[i]);
         d.gx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
-        if (d.n_slices > max_ns) max_ns = d.n_slices;
+        if (inst[i].H > max_h) max_h = inst[i].H;
     }
-    const int lds_bytes = 3 * max_ns * 256 * (int)sizeof(float);
-    if (wg > cu_count() || lds_bytes > 150 * 1024) return DSSVAE_ETOOBIG;
+    const int lds_bytes = lds_bytes_for(max_h);
     hipStream_t s = (hipStream_t)stream;
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
-    auto kern = wv == 4 ? gru_bwd_kernel<4> : gru_bwd_kernel<8>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              lds_bytes);
-    hipLaunchKernelGGL(kern, dim3(wg), dim3(64 * wv), lds_bytes, s, args);
+    void* kargs[] = {&args};
+    const hipError_t le = hipLaunchKernel(bwd_kernel(wv), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
+    if (le != hipSuccess) return (int)le;
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -24,7 +24,8 @@ class GruFwdInst(C.Structure):
     _fields_ = [("xproj", C.c_void_p), ("ldx", C.c_int64), ("whh", C.c_void_p), ("bhh", C.c_void_p),
                 ("h0", C.c_void_p), ("lengths", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("h_last", C.c_void_p), ("gates", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32),
-                ("H", C.c_int32), ("reverse", C.c_int32)]
+                ("H", C.c_int32), ("reverse", C.c_int32), ("t0", C.c_int32), ("T_total", C.c_int32),
+                ("rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GruBwdInst(C.Structure):
@@ -32,7 +33,8 @@ class GruBwdInst(C.Structure):
                 ("ldo", C.c_int64), ("gates", C.c_void_p), ("dout", C.c_void_p), ("ldd", C.c_int64),
                 ("dh_last", C.c_void_p), ("dgx", C.c_void_p), ("dgh", C.c_void_p), ("dh0", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
-                ("dbias_x", C.c_void_p), ("dbias_h", C.c_void_p)]
+                ("dbias_x", C.c_void_p), ("dbias_h", C.c_void_p), ("t0", C.c_int32), ("T_total", C.c_int32),
+                ("rows", C.c_int32), ("reserved", C.c_int32)]
 
 
 GEMM_MAX_GROUP = 8
@@ -65,6 +67,9 @@ _SIGNATURES = {
     "dssvae_gemm_f32_grouped": ([C.POINTER(GemmProblem), _I, _I, _I, _P], _I),
     "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_softmax_grad_inplace": ([_P, _L, _P, _P, _I, _I, _P, _P], _I),
+    "dssvae_ce_rowinfo": ([_P, _P, _I, _P, _P], _I),
+    "dssvae_ce_onehot_fixup": ([_P, _L, _P, _I, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P], _I),
+    "dssvae_gemm_f32_dlogits": ([_P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _F, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "dssvae_picked_logit": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _I, _P, _P], _I),
     "dssvae_linear_ce_dlogits": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P, _P], _I),
@@ -77,6 +82,7 @@ _SIGNATURES = {
     "dssvae_reparam_kl_fwd": ([_P, _P, _P, _L, _P, _P, _P], _I),
     "dssvae_reparam_kl_bwd": ([_P, _P, _P, _P, _P, _L, _P, _P, _P], _I),
     "dssvae_gru_workspace_bytes": ([_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _L),
+    "dssvae_gru_resident_workgroups": ([_I, _I, _I, C.POINTER(C.c_int)], _I),
     "dssvae_gru_fwd": ([C.POINTER(GruFwdInst), _I, _P, _L, _P], _I),
     "dssvae_gru_bwd": ([C.POINTER(GruBwdInst), _I, _P, _L, _P], _I),
     "dssvae_gru_check": ([_P, _P], _I),

@@ -193,6 +193,30 @@ def _gemm_grouped(kind, pairs, biases=None):
     return outs
 
 
+def _gemm_dlogits(slab, ldl, rows, cols, rowinfo, trans_a, B, ldb, Cm, ldc, N, beta):
+    """C (+)= dlogits(slab) . B or dlogits(slab)^T . B with the softmax gradient applied while the slab is staged"""
+    M_, K_ = (cols, rows) if trans_a else (rows, cols)
+    with _Span("gemm_store_kernel", 2.0 * M_ * N * K_, 4.0 * (M_ * K_ + N * K_ + M_ * N),
+               detail="%s dlogits M=%d N=%d K=%d%s" % ("tn" if trans_a else "nn", M_, N, K_, " +=" if beta else "")):
+        L.check(L.load().dssvae_gemm_f32_dlogits(L.ptr(slab), ldl, rows, cols, L.ptr(rowinfo), int(trans_a), L.ptr(B),
+                                                 ldb, L.ptr(Cm), ldc, N, float(beta), L.stream()),
+                "dssvae_gemm_f32_dlogits")
+
+
+_ONES_COL = {}
+
+
+def _ones_col(M, dev):
+    """[M, 4] = (1, 0, 0, 0) per row: appended to the wgrad's right operand, the bias gradient comes out of the
+    GEMM as one more output column"""
+    t = _ONES_COL.get(dev)
+    if t is None or t.size(0) < M:
+        t = torch.zeros(max(M, 8192), 4, device=dev, dtype=torch.float32)
+        t[:, 0] = 1.0
+        _ONES_COL[dev] = t
+    return t[:M]
+
+
 def colsum(x, out=None, accumulate=False):
     x, ldx = _rows(_f32(x))
     M, N = x.shape
@@ -424,6 +448,7 @@ def _col_chunks(M, N):
 CE_STREAMS = max(1, int(_os.environ.get("DSSVAE_CE_STREAMS", "1")))
 # the fused CE schedule scales stored unit gradients by row 0's upstream gradient (the caller's contract: all rows
 # receive the same one); with this flag every backward verifies it (one device sync each: tests / debugging only)
+FUSE_DLOGITS = _os.environ.get("DSSVAE_FUSE_DLOGITS", "1") != "0"  # 0: separate softmax-grad pass over the slab (A/B)
 CHECK_UNIFORM_UPSTREAM = _os.environ.get("DSSVAE_CHECK_UNIFORM", "0") == "1"
 _SIDE = {}
 
@@ -500,12 +525,22 @@ class _LinearCEFn(Function):
             # half of its dgrad GEMM)
             kx0, kx1 = (0 if need_xh else Kh), (K if need_xe else Kh)
             dx = torch.empty(M, kx1 - kx0, device=dev, dtype=torch.float32) if need_x else None
-            dW = torch.empty(N, K, device=dev, dtype=torch.float32) if need_w else None
-            db = torch.zeros(N, device=dev, dtype=torch.float32) if need_b else None
-            ones = torch.ones(M, T, device=dev, dtype=torch.float32)
+            # One target per row (the sequence decoders): the softmax gradient is applied by the dgrad / wgrad GEMMs
+            # while they stage the slab (dssvae_gemm_f32_dlogits): no pass over the slab in between, and the bias
+            # gradient is one more output column of the wgrad (a column of ones in its right operand).
+            fuse = (FUSE_DLOGITS and T == 1 and N % 4 == 0 and K % 4 == 0 and ldw % 4 == 0 and
+                    (W.data_ptr() + 4 * kx0) % 16 == 0 and (kx1 - kx0) % 4 == 0 and (need_w or not need_b))
+            Kw = K + 4 if (fuse and need_b) else K
+            dWp = torch.empty(N, Kw, device=dev, dtype=torch.float32) if need_w else None
+            db = torch.zeros(N, device=dev, dtype=torch.float32) if (need_b and not fuse) else None
+            ones = None if fuse else torch.ones(M, T, device=dev, dtype=torch.float32)
+            rowinfo = torch.empty(M, device=dev, dtype=torch.float32) if fuse else None
             xcat = None
             if need_w:
-                xcat = xh if xe is None else torch.cat((xh, xe), dim=1)
+                parts = [xh] if xe is None else [xh, xe]
+                if Kw > K:
+                    parts.append(_ones_col(M, dev))
+                xcat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
             main = torch.cuda.current_stream()
             streams = [main] + [_side_stream(dev, i) for i in range(n_str - 1)]
             for st in streams[1:]:
@@ -519,22 +554,47 @@ class _LinearCEFn(Function):
                 with torch.cuda.stream(st):
                     dl = slabs[ci % n_str][:rows]
                     _lse(xh_c, ldh, Kh, xe_c, lde, Ke, W, ldw, b, rows, N, logits=dl, lse_out=lse[m0:m0 + rows])
-                    L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, N,
-                                                            L.ptr(db), L.stream()), "dssvae_softmax_grad_inplace")
-                    L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore, L.ptr(ones[m0:]),
-                                                  rows, 0, N, L.ptr(db), L.stream()), "dssvae_onehot_sub")
-                    dlv = dl[:, :N]
-                    if need_x:
-                        mm_nn(dlv, W[:, kx0:kx1], out=dx[m0:m0 + rows])
+                    if fuse:
+                        L.check(lib.dssvae_ce_rowinfo(L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, L.ptr(rowinfo[m0:]),
+                                                      L.stream()), "dssvae_ce_rowinfo")
+                        if need_x:
+                            _gemm_dlogits(dl, ldd, rows, N, rowinfo[m0:], 0, W[:, kx0:kx1], ldw, dx[m0:m0 + rows],
+                                          dx.stride(0), kx1 - kx0, 0.0)
+                    else:
+                        L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows,
+                                                                N, L.ptr(db), L.stream()), "dssvae_softmax_grad_inplace")
+                        L.check(lib.dssvae_onehot_sub(L.ptr(dl), ldd, L.ptr(target[m0:]), T, ctx.ignore,
+                                                      L.ptr(ones[m0:]), rows, 0, N, L.ptr(db), L.stream()),
+                                "dssvae_onehot_sub")
+                        if need_x:
+                            mm_nn(dl[:, :N], W[:, kx0:kx1], out=dx[m0:m0 + rows])
                     if need_w:
                         if wg_done is not None and n_str > 1:
                             st.wait_event(wg_done)
-                        mm_tn(dlv, xcat[m0:m0 + rows], out=dW, beta=0.0 if m0 == 0 else 1.0)
-                        if n_str > 1:
-                            wg_done = torch.cuda.Event()
-                            wg_done.record(st)
+                        if fuse:
+                            _gemm_dlogits(dl, ldd, rows, N, rowinfo[m0:], 1, xcat[m0:m0 + rows], xcat.stride(0), dWp,
+                                          Kw, Kw, 0.0 if m0 == 0 else 1.0)
+                        else:
+                            mm_tn(dl[:, :N], xcat[m0:m0 + rows], out=dWp, beta=0.0 if m0 == 0 else 1.0)
+                    if fuse and (need_x or need_w):
+                        # the one-hot part of dlogits, as a correction of this chunk's two products
+                        Wp = W[:, kx0:kx1]
+                        L.check(lib.dssvae_ce_onehot_fixup(
+                            L.ptr(target[m0:]), ctx.ignore, None, rows, L.ptr(Wp) if need_x else None, ldw, kx1 - kx0,
+                            L.ptr(dx[m0:]) if need_x else None, dx.stride(0) if need_x else 0,
+                            L.ptr(xcat[m0:]) if need_w else None, xcat.stride(0) if need_w else 0, Kw,
+                            L.ptr(dWp) if need_w else None, Kw, L.stream()), "dssvae_ce_onehot_fixup")
+                    if need_w and n_str > 1:
+                        wg_done = torch.cuda.Event()
+                        wg_done.record(st)
             for st in streams[1:]:
                 main.wait_stream(st)
+            dW = None
+            if dWp is not None:
+                dW = dWp[:, :K] if Kw > K else dWp
+                if Kw > K:
+                    db = dWp[:, K]
+            ctx.dWp, ctx.db_rides = dWp, Kw > K
             ctx.unit_grads = (dx, dW, db)
             ctx.Kh, ctx.kx0 = Kh, kx0
         picked = torch.empty(M, T, device=dev, dtype=torch.float32)
@@ -548,7 +608,7 @@ class _LinearCEFn(Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            ctx.unit_grads = None
+            ctx.unit_grads = ctx.dWp = None
             return None, None, None, None, None, None, None
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         if ctx.fused:
@@ -566,9 +626,10 @@ class _LinearCEFn(Function):
                 dx.mul_(g.unsqueeze(1))
                 dxh = dx[:, :ctx.Kh] if need_xh else None  # kx0 == 0 whenever the h panel is wanted
                 dxe = dx[:, ctx.Kh - ctx.kx0:] if need_xe else None
-            if dW is not None:
-                dW.mul_(c)
-            if db is not None:
+            dWp, ctx.dWp = ctx.dWp, None
+            if dWp is not None:
+                dWp.mul_(c)   # dW (and db when it rode along as a column) in one pass
+            if db is not None and not ctx.db_rides:
                 db.mul_(c)
             return dxh, dxe, dW, db, None, None, None
         # general path: per chunk of vocabulary columns, recompute dlogits into a

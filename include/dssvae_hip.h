@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step */
+#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -95,6 +95,25 @@ int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe,
  * of autograd(log_softmax + gather) (decoder/rnn_decoder.py:94-102). */
 int dssvae_softmax_grad_inplace(float* X, int64_t ldx, const float* lse, const float* coef, int M, int N,
                                 float* colsum, void* stream);
+
+/* The two consumers of a logits slab with the softmax part of the gradient applied WHILE THE SLAB TILE IS STAGED
+ * (no separate pass over the slab, nothing written back): with P[m,n] = coef[m] * exp(logits[m,n] - lse[m]),
+ *   trans_a = 0:  C[rows, N] (+)= P . B          B [cols, N] row-major   (dgrad: B = W_out panel)
+ *   trans_a = 1:  C[cols, N] (+)= P^T . B        B [rows, N] row-major   (wgrad: B = [h | e | 1 0 0 0]: the column of
+ *                                                ones makes the bias gradient come out as one more output column)
+ * beta in {0, 1}.  rowinfo [rows] = (lse - ln coef) * log2(e) per slab row (+inf where coef = 0), written by
+ * dssvae_ce_rowinfo.  The one-hot part of dlogits (dL[m, target[m]] -= w[m]) is applied to the PRODUCTS by
+ * dssvae_ce_onehot_fixup: dX[m,:] -= w W_panel[target[m],:] and dW[target[m],:] -= w Xc[m,:] (w = g[m], or 1 when g
+ * is NULL; rows whose target is ignore_index are skipped; dX or dW may be NULL).
+ * The slab and B must be 16-byte aligned with leading dimensions / cols / N multiples of 4, else DSSVAE_ETOOBIG
+ * (the caller then uses dssvae_softmax_grad_inplace + dssvae_onehot_sub + dssvae_gemm_f32).
+ * Replaces autograd of log_softmax + gather + the Linear's backward (decoder/rnn_decoder.py:70-73,94-102). */
+int dssvae_ce_rowinfo(const float* lse, const float* coef, int M, float* rowinfo, void* stream);
+int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int rows, int cols, const float* rowinfo, int trans_a,
+                            const float* B, int64_t ldb, float* C, int64_t ldc, int N, float beta, void* stream);
+int dssvae_ce_onehot_fixup(const int64_t* target, int64_t ignore_index, const float* g, int rows,
+                           const float* W_panel, int64_t ldw, int Kx, float* dX, int64_t lddx,
+                           const float* Xc, int64_t ldxc, int Kw, float* dW, int64_t lddw, void* stream);
 
 /* lse[m] = log sum_n exp(logit[m,n]) from the split partials; argmax[m] (may be NULL). */
 int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg,
@@ -178,6 +197,15 @@ typedef struct {
     float* out; int64_t ldo;
     float* h_last; float* gates;
     int32_t B, T, H, reverse;
+    /* A launch may run a SEGMENT of the recurrence: steps t0 .. t0 + T - 1 (in the order the recurrence walks
+     * them) of T_total steps; xproj / out / gates are then [B, T_total, .] and h0 / h_last the states at the
+     * segment's ends.  T_total = 0: the whole recurrence (t0 must be 0).  The caller chains segments on one
+     * stream (different instances of a layer end at different steps: the long ones get the chip to themselves,
+     * re-cut into smaller cells, once the short ones are done). */
+    int32_t t0, T_total;
+    /* batch rows per workgroup ("cell" = rows x 16 hidden units): 16, 32, 64 or 128; 0 = the library chooses for
+     * the launch (64 when the grid is resident that way, else 128) */
+    int32_t rows, reserved;
 } dssvae_gru_fwd_inst;
 
 typedef struct {
@@ -192,9 +220,17 @@ typedef struct {
     /* optional, ACCUMULATED into (caller zero-fills): bias gradients [3H] = column sums of dgx / dgh over
      * batch and time (grad of b_ih / b_hh), so that no separate reduction pass reads dgx / dgh again */
     float* dbias_x; float* dbias_h;
+    /* segment of the recurrence and cell height, as in dssvae_gru_fwd_inst: this launch walks forward steps
+     * t0 + T - 1 down to t0; dh_last / dh0 are the gradients wrt the states at the segment's ends */
+    int32_t t0, T_total;
+    int32_t rows, reserved;
 } dssvae_gru_bwd_inst;
 
 int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host);
+/* Workgroups of a persistent launch the device holds at once (every one must be resident: the hand-off spins on
+ * peers): the runtime's occupancy for the kernel at this LDS slice (largest H of the launch) and block size
+ * (largest cell height: 16 rows per wave) x the CU count.  A launch whose grid exceeds it returns DSSVAE_ETOOBIG. */
+int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host);
 int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst_host, int n_inst, void* workspace,
                    int64_t workspace_bytes, void* stream);
 int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst_host, int n_inst, void* workspace,
