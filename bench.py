@@ -235,6 +235,9 @@ def main():
     dt = time.perf_counter() - t0
     ops.PROFILE = None
     ops.check_persistent_errors()
+    if a.shapes:
+        sys.stderr.write("gradients adopted in place %d, copied into the flat buffer %d (all steps)\n"
+                         % (opt.adopted, opt.copied))
     loss = float(torch.mean(ret["Loss"]).item())
     if world > 1:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)

@@ -77,6 +77,20 @@ def n_cus():
     return _CUS
 
 
+# Gradient sink: an optimiser that keeps all gradients in one flat buffer (train.FlatAdam) installs itself here.
+# A backward that produces the gradient of a PARAMETER asks `_claim(param)` for that parameter's slice of the
+# flat buffer, computes straight into it and returns the slice as the gradient: autograd's AccumulateGrad then
+# adopts the tensor (p.grad is None at that point) instead of launching an add kernel per parameter.
+GRAD_SINK = None  # weakref.ref to the optimiser
+
+
+def _claim(t, need=True):
+    if not need or GRAD_SINK is None or t is None:
+        return None
+    sink = GRAD_SINK()
+    return None if sink is None else sink.claim(t)
+
+
 def _f32(t):
     if t.dtype != torch.float32:
         raise RuntimeError("expected float32, got %s" % t.dtype)
@@ -145,7 +159,7 @@ def mm_tn(dy, x, out=None, beta=0.0):
     return out
 
 
-def _gemm_grouped(kind, pairs, biases=None):
+def _gemm_grouped(kind, pairs, biases=None, outs_given=None):
     """kind 'nt': x[M,K] @ w[N,K]^T (+bias) | 'nn': dy[M,N] @ w[N,K] | 'tn': dy[M,N]^T @ x[M,K], for a list
     of (left, right) operand pairs, in as few launches as the group limit allows; -> list of outputs
     (views of one buffer)."""
@@ -166,10 +180,15 @@ def _gemm_grouped(kind, pairs, biases=None):
         probs.append((l, ldl, r, ldr, M, N, K, None if biases is None else biases[i]))
     L.require_cuda(*[p[0] for p in probs])
     dev = probs[0][0].device
-    sizes = [(p[4] * p[5] + 3) // 4 * 4 for p in probs]
+    given = [None] * len(probs) if outs_given is None else list(outs_given)
+    sizes = [0 if given[i] is not None else (p[4] * p[5] + 3) // 4 * 4 for i, p in enumerate(probs)]
     buf = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
     outs, off = [], 0
-    for p, n in zip(probs, sizes):
+    for i, (p, n) in enumerate(zip(probs, sizes)):
+        if given[i] is not None:
+            assert given[i].shape == (p[4], p[5]) and given[i].is_contiguous()
+            outs.append(given[i])
+            continue
         outs.append(buf[off:off + p[4] * p[5]].view(p[4], p[5]))
         off += n
     lib = L.load()
@@ -240,6 +259,7 @@ class _LinearFn(Function):
         x2 = x.reshape(-1, x.size(-1))
         ctx.save_for_backward(x2, w)
         ctx.has_bias = b is not None
+        ctx.bias_ref = b  # not needed for the math: identifies the parameter whose gradient slice the backward fills
         ctx.xshape = x.shape
         return mm_nt(x2, w, b).view(*x.shape[:-1], w.size(0))
 
@@ -250,8 +270,8 @@ class _LinearFn(Function):
         x2, w = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.size(-1)).contiguous()
         dx = mm_nn(dy2, w).view(ctx.xshape) if ctx.needs_input_grad[0] else None
-        dw = mm_tn(dy2, x2) if ctx.needs_input_grad[1] else None
-        db = colsum(dy2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        dw = mm_tn(dy2, x2, out=_claim(w)) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2, out=_claim(ctx.bias_ref)) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
         return dx, dw, db
 
 
@@ -272,6 +292,7 @@ class _LinearManyFn(Function):
         outs = _gemm_grouped("nt", list(zip(x2, ws)), biases=[b.contiguous() for b in bs])
         ctx.save_for_backward(*x2, *ws)
         ctx.n = len(xs)
+        ctx.bias_refs = list(bs)
         ctx.xshapes = [x.shape for x in xs]
         return tuple(o.view(*x.shape[:-1], w.size(0)) for o, x, w in zip(outs, xs, ws))
 
@@ -285,11 +306,12 @@ class _LinearManyFn(Function):
         ix = [i for i in range(n) if dy2[i] is not None and need[3 * i]]
         iw = [i for i in range(n) if dy2[i] is not None and need[3 * i + 1]]
         dxs = dict(zip(ix, _gemm_grouped("nn", [(dy2[i], ws[i]) for i in ix]))) if ix else {}
-        dws = dict(zip(iw, _gemm_grouped("tn", [(dy2[i], x2[i]) for i in iw]))) if iw else {}
+        dws = dict(zip(iw, _gemm_grouped("tn", [(dy2[i], x2[i]) for i in iw],
+                                         outs_given=[_claim(ws[i]) for i in iw]))) if iw else {}
         out = []
         for i in range(n):
             dx = dxs[i].view(ctx.xshapes[i]) if i in dxs else None
-            db = colsum(dy2[i]) if (dy2[i] is not None and need[3 * i + 2]) else None
+            db = colsum(dy2[i], out=_claim(ctx.bias_refs[i])) if (dy2[i] is not None and need[3 * i + 2]) else None
             out += [dx, dws.get(i), db]
         return tuple(out)
 
@@ -319,6 +341,7 @@ class _EmbedFn(Function):
                                              L.ptr(out), E, L.stream()), "dssvae_embed_gather")
         ctx.save_for_backward(flat, mask)
         ctx.tshape = table.shape
+        ctx.table_ref = table
         return out.view(*ids.shape, E)
 
     @staticmethod
@@ -328,7 +351,11 @@ class _EmbedFn(Function):
             return None, None, None
         V, E = ctx.tshape
         g2 = g.reshape(-1, E).contiguous()
-        dt = torch.zeros(V, E, device=g.device, dtype=torch.float32)
+        # the table's slice of the flat gradient buffer (zero so far) when this is its first use in the step;
+        # further uses of a shared table scatter into a temporary and autograd sums
+        dt = _claim(ctx.table_ref)
+        if dt is None:
+            dt = torch.zeros(V, E, device=g.device, dtype=torch.float32)
         L.check(L.load().dssvae_embed_scatter_add(L.ptr(dt), E, L.ptr(flat), flat.numel(), E, L.ptr(mask),
                                                   L.ptr(g2), E, L.stream()), "dssvae_embed_scatter_add")
         return dt, None, None
@@ -595,6 +622,7 @@ class _LinearCEFn(Function):
                 if Kw > K:
                     db = dWp[:, K]
             ctx.dWp, ctx.db_rides = dWp, Kw > K
+            ctx.param_refs = (W, b)
             ctx.unit_grads = (dx, dW, db)
             ctx.Kh, ctx.kx0 = Kh, kx0
         picked = torch.empty(M, T, device=dev, dtype=torch.float32)
@@ -608,7 +636,7 @@ class _LinearCEFn(Function):
     @staticmethod
     def backward(ctx, g):
         if g is None:
-            ctx.unit_grads = ctx.dWp = None
+            ctx.unit_grads = ctx.dWp = ctx.param_refs = None
             return None, None, None, None, None, None, None
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         if ctx.fused:
@@ -627,10 +655,16 @@ class _LinearCEFn(Function):
                 dxh = dx[:, :ctx.Kh] if need_xh else None  # kx0 == 0 whenever the h panel is wanted
                 dxe = dx[:, ctx.Kh - ctx.kx0:] if need_xe else None
             dWp, ctx.dWp = ctx.dWp, None
-            if dWp is not None:
-                dWp.mul_(c)   # dW (and db when it rode along as a column) in one pass
-            if db is not None and not ctx.db_rides:
-                db.mul_(c)
+            W_ref, b_ref = ctx.param_refs
+            ctx.param_refs = None
+            if dW is not None:
+                gW = _claim(W_ref)
+                # c * (unit gradient), written into the parameter's slice of the flat gradient buffer when there
+                # is one (one pass: no scaled temporary, no accumulate kernel behind it)
+                dW = torch.mul(dW, c, out=gW) if gW is not None else dW.mul_(c)
+            if db is not None:
+                gb = _claim(b_ref)
+                db = torch.mul(db, c, out=gb) if gb is not None else (db * c if ctx.db_rides else db.mul_(c))
             return dxh, dxe, dW, db, None, None, None
         # general path: per chunk of vocabulary columns, recompute dlogits into a
         # slab [M, nc] (+ the bias gradient by column sums in the same kernel), subtract the one-hot part,
@@ -904,6 +938,7 @@ class _GruFn(Function):
             if meta.get("check"):
                 L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
+        ctx.bias_refs = (list(tensors[2::5]), list(tensors[4::5]))  # identify the parameters for _claim
         ctx.h0_none = [h is None for h in h0s]
         ctx.save_for_backward(*ws, *[h for h in h0s if h is not None], *[g for g in gates if g is not None])
         ctx.gate_slot = [sum(1 for g in gates[:i] if g is not None) if gates[i] is not None else -1 for i in range(n)]
@@ -934,8 +969,15 @@ class _GruFn(Function):
         # bias gradients (column sums of dgx / dgh) are accumulated by the persistent kernel itself
         need_bx = [i in live and ctx.needs_input_grad[5 + 5 * i] for i in range(n)]
         need_bh = [i in live and ctx.needs_input_grad[3 + 5 * i] for i in range(n)]
-        dbx = [torch.zeros(3 * Hs[i], device=dev, dtype=torch.float32) if need_bx[i] else None for i in range(n)]
-        dbh = [torch.zeros(3 * Hs[i], device=dev, dtype=torch.float32) if need_bh[i] else None for i in range(n)]
+        # (accumulated with atomics: a claimed slice of the flat gradient buffer is zero at this point, see _claim)
+        bhh_refs, bih_refs = ctx.bias_refs
+
+        def _bias_buf(ref, H):
+            g = _claim(ref)
+            return g if g is not None else torch.zeros(3 * H, device=dev, dtype=torch.float32)
+
+        dbx = [_bias_buf(bih_refs[i], Hs[i]) if need_bx[i] else None for i in range(n)]
+        dbh = [_bias_buf(bhh_refs[i], Hs[i]) if need_bh[i] else None for i in range(n)]
         lib = L.load()
         for i in live:
             if not ctx.fit[i]:
@@ -974,7 +1016,7 @@ class _GruFn(Function):
         for i in iw:
             rows = BT[i][0] * BT[i][1]
             pairs.append((dgh[i].view(rows, 3 * Hs[i]), gates[i].view(rows, 5 * Hs[i])[:, 4 * Hs[i]:]))
-        dws = dict(zip(iw, _gemm_grouped("tn", pairs))) if iw else {}
+        dws = dict(zip(iw, _gemm_grouped("tn", pairs, outs_given=[_claim(ws[i]) for i in iw]))) if iw else {}
         out = [None]
         for i in range(n):
             if dgx[i] is None:

@@ -121,6 +121,11 @@ class GradBuckets(object):
         else:
             self.works.append((dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True), chunk))
 
+    def already_sent(self, i):
+        """has parameter i's bucket been dealt with (sent or skipped) in this step?  Its slice of the flat
+        buffer must then not be written directly: the gradient has to go through intercept()."""
+        return self.expect is not None and self.bucket_of[i] < self.next
+
     def intercept(self, i, g):
         """tensor hook of parameter i (runs before the gradient is accumulated): a gradient for a bucket that
         has already been sent or skipped is kept aside and replaced by zeros, so the bucket's averaged slice

@@ -52,13 +52,20 @@ class FlatAdam(object):
         self.m = torch.zeros(total, device=dev)
         self.v = torch.zeros(total, device=dev)
         self.offsets, off = [], 0
-        for p, n in zip(params, sizes):
+        self.views = []   # parameter i's slice of the flat gradient buffer
+        self._by_ptr = {}
+        for i, (p, n) in enumerate(zip(params, sizes)):
             view = self.flat[off:off + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
-            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+            self.views.append(self.grad[off:off + p.numel()].view(p.shape))
+            self._by_ptr[p.data_ptr()] = i
+            p.grad = None
             self.offsets.append(off)
             off += n
+        self.claimed = set()
+        self.adopted = 0   # gradients that autograd adopted in place (observability / tests)
+        self.copied = 0    # gradients produced outside the flat buffer and copied in
         self.sizes = sizes
         self.params, self.betas, self.eps, self.clip = params, betas, eps, clip_grad
         self.param_groups = [{"lr": lr}]  # the reference's lr decay writes optimizer.param_groups[0]['lr']
@@ -78,8 +85,10 @@ class FlatAdam(object):
             # got no gradient this step); a leaf frozen after its use still gets the call but accumulates
             # nothing.  (A post-accumulate hook fires in all of these cases alike.)
             p.register_hook(lambda g, i=i: self._on_arrive(i, g))
-            if self.buckets is not None:
-                p.register_post_accumulate_grad_hook(lambda _p, i=i: self.buckets.mark_ready(i))
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._on_accumulated(i))
+        import weakref
+        self._self_ref = weakref.ref(self)
+        ops.GRAD_SINK = self._self_ref  # the newest optimiser takes the gradients of its parameters (ops._claim)
 
     @property
     def lr(self):
@@ -99,20 +108,50 @@ class FlatAdam(object):
 
     def zero_grad(self, tag="main"):
         """tag: kind of step that follows (steps of one kind share an autograd graph shape; the
-        data-parallel bucket schedule is learned per kind)."""
+        data-parallel bucket schedule is learned per kind).  Every p.grad becomes None: a backward that
+        fills a parameter's slice of the flat buffer itself (ops._claim) hands that slice to autograd, which
+        adopts it as p.grad without an accumulate kernel; anything else is copied in (_on_accumulated)."""
         self.grad.zero_()
         self.fired = set()
-        for p in self.params:  # autograd may have replaced a view (e.g. after requires_grad toggling)
-            if p.grad is None or p.grad.data_ptr() < self.grad.data_ptr() or \
-                    p.grad.data_ptr() >= self.grad.data_ptr() + self.grad.numel() * 4:
-                self._rebind()
-                break
+        self.claimed = set()
+        ops.GRAD_SINK = self._self_ref
+        for p in self.params:
+            p.grad = None
         if self.buckets is not None:
             self.buckets.reset(tag)
 
-    def _rebind(self):
-        for p, off in zip(self.params, self.offsets):
-            p.grad = self.grad[off:off + p.numel()].view(p.shape)
+    def claim(self, t):
+        """ops._claim: the slice of the flat gradient buffer that belongs to parameter tensor `t` (zero at this
+        point), or None -- not one of this optimiser's parameters, frozen by now (its gradient is to be
+        dropped, as AccumulateGrad does), already handed out in this step (a second use of the parameter:
+        autograd sums the contributions), or its data-parallel bucket is already on the wire."""
+        i = self._by_ptr.get(t.data_ptr())
+        if i is None or i in self.claimed:
+            return None
+        p = self.params[i]
+        if t.shape != p.shape or not t.is_contiguous() or not p.requires_grad:
+            return None
+        if self.buckets is not None and self.buckets.already_sent(i):
+            return None
+        self.claimed.add(i)
+        return self.views[i].view(p.shape)  # a tensor of its own: autograd adopts a gradient nobody else holds
+
+    def _on_accumulated(self, i):
+        """post-accumulate hook: parameter i's gradient is complete.  Bring it home if it was produced outside
+        the flat buffer (a torch op's gradient, or contributions summed by the engine), then report it to the
+        data-parallel schedule."""
+        p = self.params[i]
+        g, view = p.grad, self.views[i]
+        if g is not None:
+            late = self.buckets is not None and i in self.buckets.late
+            if g.data_ptr() == view.data_ptr():
+                self.adopted += 1
+            elif not late:  # a late gradient was taken aside by intercept(): p.grad holds its zero stand-in
+                view.copy_(g)
+                self.copied += 1
+            p.grad = view
+        if self.buckets is not None:
+            self.buckets.mark_ready(i)
 
     def all_reduce_grads(self):
         """gradient average over RCCL (xGMI): buckets not yet sent by the backward hooks go now."""
