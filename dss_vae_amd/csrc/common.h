@@ -63,3 +63,39 @@ static inline int dssvae_zero2d(float* p, int64_t ld, int rows, int cols, hipStr
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
+
+// The same for up to 8 buffers in ONE launch (the split-K outputs of a grouped GEMM: a launch each cost ~4.5 us).
+struct DssvaeZeroMany {
+    float* p[8]; int64_t ld[8]; int rows[8], cols[8], vec[8], blk_begin[9];
+    int n;
+};
+static __global__ void dssvae_zero_many_kernel(DssvaeZeroMany z) {
+    int i = 0;
+    while (i + 1 < z.n && (int)blockIdx.x >= z.blk_begin[i + 1]) ++i;
+    const int n4 = (z.cols[i] + 3) >> 2;
+    const int64_t g = (int64_t)((int)blockIdx.x - z.blk_begin[i]) * blockDim.x + threadIdx.x;
+    if (g >= (int64_t)z.rows[i] * n4) return;
+    const int r = (int)(g / n4), c = 4 * (int)(g % n4);
+    float* q = z.p[i] + (int64_t)r * z.ld[i] + c;
+    if (z.vec[i]) {
+        *reinterpret_cast<float4*>(q) = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (c + j < z.cols[i]) q[j] = 0.f;
+    }
+}
+static inline void dssvae_zero_many_add(DssvaeZeroMany& z, float* p, int64_t ld, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return;
+    const int i = z.n++;
+    z.p[i] = p; z.ld[i] = ld; z.rows[i] = rows; z.cols[i] = cols;
+    z.vec[i] = aligned16(p) && (ld % 4) == 0 && (cols % 4) == 0;
+    const int64_t n = (int64_t)rows * ((cols + 3) >> 2);
+    z.blk_begin[i + 1] = z.blk_begin[i] + (int)((n + 255) / 256);
+}
+static inline int dssvae_zero_many_launch(const DssvaeZeroMany& z, hipStream_t s) {
+    if (z.n == 0) return DSSVAE_OK;
+    hipLaunchKernelGGL(dssvae_zero_many_kernel, dim3((unsigned)z.blk_begin[z.n]), dim3(256), 0, s, z);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}

@@ -766,6 +766,65 @@ __global__ void picked_logit_kernel(const float* __restrict__ Xh, int64_t ldh, i
     if (lane == 0) picked[idx] = s + (bias ? bias[tg] : 0.f);
 }
 
+// cnt[m] = number of targets of row m that are not ignore_index (the row's weight in the loss), as float
+__global__ void ce_count_kernel(const int64_t* __restrict__ target, int T, int64_t ignore, int M,
+                                float* __restrict__ cnt) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= M) return;
+    int c = 0;
+    for (int t = 0; t < T; ++t) c += target[(int64_t)m * T + t] != ignore;
+    cnt[m] = (float)c;
+}
+
+// nll[m] = sum over the row's targets t of (lse[m] - logit[m, target[m,t]]), ignored targets skipped.  A wave per
+// (row, target) dot product: WPR waves share a row (WPR = 1 for the sequence decoders' one target per row, 4 for the
+// bag-of-words heads' T targets per row: wave w takes targets w, w + 4, ...); partials meet in LDS, fixed order.
+template <int WPR>
+__global__ __launch_bounds__(256) void ce_row_nll_kernel(const float* __restrict__ Xh, int64_t ldh, int Kh,
+                                                         const float* __restrict__ Xe, int64_t lde, int Ke,
+                                                         const float* __restrict__ W, int64_t ldw,
+                                                         const float* __restrict__ bias,
+                                                         const int64_t* __restrict__ target, int T, int64_t ignore,
+                                                         const float* __restrict__ lse, int M,
+                                                         float* __restrict__ nll) {
+    __shared__ float red[4];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    float acc = 0.f;
+    if (m < M) {
+        const float l = lse[m];
+        for (int t = WPR == 1 ? 0 : wave; t < T; t += WPR) {
+            const int64_t tg = target[(int64_t)m * T + t];
+            if (tg == ignore) continue;
+            const float* w = W + tg * ldw;
+            float d = 0.f;
+            for (int k = lane; k < Kh; k += 64) d += Xh[(int64_t)m * ldh + k] * w[k];
+            for (int k = lane; k < Ke; k += 64) d += Xe[(int64_t)m * lde + k] * w[Kh + k];
+            d = wave_sum(d);
+            acc += l - (d + (bias ? bias[tg] : 0.f));
+        }
+    }
+    if (WPR == 1) {
+        if (lane == 0 && m < M) nll[m] = acc;
+    } else {
+        if (lane == 0) red[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0 && m < M) nll[m] = (red[0] + red[1]) + (red[2] + red[3]);
+    }
+}
+
+// out[s] = sum of nll[s*group .. s*group+group-1]: one wave per sentence, fixed order
+__global__ void ce_group_sum_kernel(const float* __restrict__ nll, int M, int group, int S, float* __restrict__ out) {
+    const int s = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (s >= S) return;
+    const int lane = threadIdx.x & 63;
+    const int m0 = s * group, m1 = min(M, m0 + group);
+    float acc = 0.f;
+    for (int m = m0 + lane; m < m1; m += 64) acc += nll[m];
+    acc = wave_sum(acc);
+    if (lane == 0) out[s] = acc;
+}
+
 __global__ void onehot_sub_kernel(float* __restrict__ dL, int64_t ldd, const int64_t* __restrict__ target,
                                   int64_t ignore, const float* __restrict__ g, int64_t total, int T, int64_t n0,
                                   int64_t n1, float* __restrict__ colsum) {
@@ -954,6 +1013,8 @@ int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t
         if (wgs <= slots || ktps >= nk_max) break;
     }
     int wg = 0;
+    DssvaeZeroMany zm;
+    zm.n = 0; zm.blk_begin[0] = 0;
     for (int i = 0; i < n; ++i) {
         GroupProblem& q = g.p[i];
         const int nk = (pr[i].K + BK - 1) / BK;
@@ -962,10 +1023,11 @@ int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t
         q.ksplit = (nk + q.ktps - 1) / q.ktps;
         q.wg_begin = wg;
         wg += ((pr[i].M + BM - 1) / BM) * q.tiles_n * q.ksplit;
-        if (q.ksplit > 1) {
-            const int e = dssvae_zero2d(q.C, q.ldc, q.M, q.N, s);
-            if (e != DSSVAE_OK) return e;
-        }
+        if (q.ksplit > 1) dssvae_zero_many_add(zm, q.C, q.ldc, q.M, q.N);  // all split outputs in one fill launch
+    }
+    {
+        const int e = dssvae_zero_many_launch(zm, s);
+        if (e != DSSVAE_OK) return e;
     }
     constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
     auto kern = gemm_group_kernel<TA, TB, VW, WM, WN>;
@@ -1178,4 +1240,35 @@ extern "C" int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int row
     // C[cols, N] = dlogits^T . B                   (contraction over the slab rows)
     a.K1 = rows;
     return launch_store_tile<true, true, 4, true>(a, b, C, ldc, nullptr, cols, N, rows, 1.f, beta, 0, s);
+}
+
+extern "C" int dssvae_ce_count(const int64_t* target, int T, int64_t ignore_index, int M, float* cnt, void* stream) {
+    if (!target || !cnt || M <= 0 || T <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(ce_count_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, target, T,
+                       ignore_index, M, cnt);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_ce_finish(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                                const float* W, int64_t ldw, const float* bias, const int64_t* target, int T,
+                                int64_t ignore_index, const float* lse, int M, int group, float* row_nll, float* out,
+                                void* stream) {
+    if (!Xh || !W || !target || !lse || !out || M <= 0 || T <= 0 || Kh <= 0 || group <= 0 || (Ke > 0 && !Xe) ||
+        (group > 1 && !row_nll))
+        return DSSVAE_EINVAL;
+    hipStream_t s = (hipStream_t)stream;
+    if (T == 1)
+        hipLaunchKernelGGL(ce_row_nll_kernel<1>, dim3((M + 3) / 4), dim3(256), 0, s, Xh, ldh, Kh, Xe, lde, Ke, W, ldw,
+                           bias, target, T, ignore_index, lse, M, group > 1 ? row_nll : out);
+    else
+        hipLaunchKernelGGL(ce_row_nll_kernel<4>, dim3(M), dim3(256), 0, s, Xh, ldh, Kh, Xe, lde, Ke, W, ldw, bias,
+                           target, T, ignore_index, lse, M, group > 1 ? row_nll : out);
+    DSSVAE_CHECK_LAUNCH();
+    if (group > 1) {
+        const int S = (M + group - 1) / group;
+        hipLaunchKernelGGL(ce_group_sum_kernel, dim3((S + 3) / 4), dim3(256), 0, s, row_nll, M, group, S, out);
+        DSSVAE_CHECK_LAUNCH();
+    }
+    return DSSVAE_OK;
 }

@@ -36,6 +36,14 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p
         mask[i] = u01(seed, (uint64_t)i) < p ? 0.f : scale;
 }
 
+// y = x * keep-mask(seed) / (1 - p): the mask is a function of (seed, element index), so backward regenerates
+// it from the seed (dx = dy * mask) and no mask tensor ever exists
+__global__ void dropout_apply_kernel(const float* __restrict__ x, int64_t n, float p, float scale, uint64_t seed,
+                                     float* __restrict__ y) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = u01(seed, (uint64_t)i) < p ? 0.f : x[i] * scale;
+}
+
 __global__ void unk_replace_kernel(const int64_t* __restrict__ ids, int64_t n, const float* __restrict__ rnd,
                                    float rate, uint64_t seed, int64_t sos, int64_t pad, int64_t eos, int64_t unk,
                                    int64_t* __restrict__ out) {
@@ -241,6 +249,14 @@ extern "C" int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t see
     if (!mask || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p,
                        1.f / (1.f - p), seed);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, n, p,
+                       1.f / (1.f - p), seed, y);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

@@ -52,7 +52,7 @@ class RNNDecoder(RNNBase):
         x, hl = emb, []
         for layer in range(self.n_layers):
             if layer > 0 and self.training and self.rnn_droprate > 0.0:
-                x = x * ops.dropout_mask(tuple(x.shape), self.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
+                x = ops.dropout(x, self.rnn_droprate, GLOBAL_SEEDS.next())
             wih, whh, bih, bhh = self.rnn.layer_params(layer)
             (x,), (h,) = ops.gru_layer([dict(xproj=ops.linear(x, wih, bih), whh=whh, bhh=bhh, h0=h0[layer],
                                              group=0, col=0)])
@@ -147,6 +147,9 @@ def score_many(jobs):
         e = prepare_job(j)["_emb"]
         embs.append(e)
         xs.append(e)
+    # per-layer initial states: ONE unbind per head (its backward is one stack) instead of a select per layer
+    # (whose backward is a zero-fill + copy per layer and an add to join them)
+    h0_layers = [j["h0"].unbind(0) for j in jobs]
     for layer in range(n_layers):
         insts, proj = [], {True: [], False: []}
         for k, j in enumerate(jobs):
@@ -154,9 +157,9 @@ def score_many(jobs):
             ng = bool(j.get("no_grad")) or not grad_on
             with torch.set_grad_enabled(not ng):
                 if layer > 0 and dec.training and dec.rnn_droprate > 0.0:
-                    x = x * ops.dropout_mask(tuple(x.shape), dec.rnn_droprate, GLOBAL_SEEDS.next(), x.device)
+                    x = ops.dropout(x, dec.rnn_droprate, GLOBAL_SEEDS.next())
             wih, whh, bih, bhh = dec.rnn.layer_params(layer)
-            h0 = j["h0"][layer]
+            h0 = h0_layers[k][layer]
             if ng:
                 whh, bhh, h0 = whh.detach(), bhh.detach(), h0.detach()
             proj[ng].append((k, (x, wih, bih.detach())))  # b_ih's gradient comes out of the recurrence's backward
@@ -179,13 +182,15 @@ def score_many(jobs):
             xh, xe = xs[k].reshape(B * T, H), embs[k].reshape(B * T, -1)
             uni = bool(j.get("uniform")) and not j.get("norm_by_word")
             if keep is None:
-                nll = ops.linear_ce(xh, xe, dec.out.weight, dec.out.bias, gold, dec.pad_id, uniform_upstream=uni)
+                # the T rows of a sentence are summed by the loss kernel itself
+                logp = -ops.linear_ce(xh, xe, dec.out.weight, dec.out.bias, gold, dec.pad_id, uniform_upstream=uni,
+                                      group=T)
             else:
                 # pad rows add nothing to the loss or to any gradient: leave them out of the projection
                 part = ops.linear_ce(xh.index_select(0, keep), xe.index_select(0, keep), dec.out.weight,
                                      dec.out.bias, gold.index_select(0, keep), dec.pad_id, uniform_upstream=uni)
                 nll = torch.zeros(B * T, device=part.device, dtype=part.dtype).index_copy(0, keep, part)
-            logp = -nll.view(B, T).sum(1)
+                logp = -nll.view(B, T).sum(1)
             if j.get("norm_by_word"):
                 logp = logp.div(j["targets"].ne(dec.pad_id).sum(dim=-1).float())
         res.append(logp)

@@ -56,7 +56,7 @@ def encode_many(encoders, input_var, input_lengths=None):
         for ei, e in enumerate(encoders):
             x = xs[ei]
             if layer > 0 and e.training and e.rnn_droprate > 0.0:
-                x = x * ops.dropout_mask(tuple(x.shape), e.rnn_droprate, GLOBAL_SEEDS.next(), dev)
+                x = ops.dropout(x, e.rnn_droprate, GLOBAL_SEEDS.next())
             for di, suffix in enumerate(e.rnn.suffixes()):
                 wih, whh, bih, bhh = e.rnn.layer_params(layer, suffix)
                 proj.append((x, wih, bih.detach()))  # b_ih's gradient comes out of the recurrence's backward

@@ -78,6 +78,9 @@ _SIGNATURES = {
     "dssvae_embed_gather": ([_P, _L, _P, _I, _I, _P, _P, _L, _P], _I),
     "dssvae_embed_scatter_add": ([_P, _L, _P, _I, _I, _P, _P, _L, _P], _I),
     "dssvae_dropout_mask": ([_P, _L, _F, _U64, _P], _I),
+    "dssvae_dropout_apply": ([_P, _L, _F, _U64, _P, _P], _I),
+    "dssvae_ce_count": ([_P, _I, _L, _I, _P, _P], _I),
+    "dssvae_ce_finish": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _P, _I, _I, _P, _P, _P], _I),
     "dssvae_unk_replace": ([_P, _L, _P, _F, _U64, _L, _L, _L, _L, _P, _P], _I),
     "dssvae_reparam_kl_fwd": ([_P, _P, _P, _L, _P, _P, _P], _I),
     "dssvae_reparam_kl_bwd": ([_P, _P, _P, _P, _P, _L, _P, _P, _P], _I),

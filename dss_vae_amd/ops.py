@@ -372,6 +372,38 @@ def dropout_mask(shape, p, seed, device):
     return m
 
 
+class _DropoutFn(Function):
+    """y = x * mask(p, seed) / (1 - p); the mask is regenerated from the seed in backward (never stored)"""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        L.require_cuda(x)
+        ctx.set_materialize_grads(False)
+        x = _f32(x).contiguous()
+        y = torch.empty_like(x)
+        ctx.p, ctx.seed = float(p), int(seed) & (2 ** 64 - 1)
+        L.check(L.load().dssvae_dropout_apply(L.ptr(x), x.numel(), ctx.p, ctx.seed, L.ptr(y), L.stream()),
+                "dssvae_dropout_apply")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if dy is None:
+            return None, None, None
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        L.check(L.load().dssvae_dropout_apply(L.ptr(dy), dy.numel(), ctx.p, ctx.seed, L.ptr(dx), L.stream()),
+                "dssvae_dropout_apply")
+        return dx, None, None
+
+
+def dropout(x, p, seed):
+    """nn.Dropout(p) in train mode with the mask of dropout_mask(x.shape, p, seed), in one launch each way"""
+    if not p > 0.0 or x.numel() == 0:
+        return x
+    return _DropoutFn.apply(x, p, seed)
+
+
 def unk_replace(ids, rate, entry, rand=None, seed=0):
     """word dropout on device (utils/nn_funcs.py:13-23)."""
     if not rate > 0.0:
@@ -510,7 +542,7 @@ class _LinearCEFn(Function):
       recompute ~7x dearer than the slab round trip through the cache."""
 
     @staticmethod
-    def forward(ctx, xh, xe, W, b, target, ignore_index, uniform):
+    def forward(ctx, xh, xe, W, b, target, ignore_index, uniform, group):
         L.require_cuda(xh, W, target)
         ctx.set_materialize_grads(False)
         xh, ldh = _rows(_f32(xh))
@@ -528,7 +560,10 @@ class _LinearCEFn(Function):
         T = target.size(1)
         dev = xh.device
         lib = L.load()
-        cnt = (target != ignore_index).sum(1).to(torch.float32)
+        cnt = torch.empty(M, device=dev, dtype=torch.float32)
+        L.check(lib.dssvae_ce_count(L.ptr(target), T, int(ignore_index), M, L.ptr(cnt), L.stream()), "dssvae_ce_count")
+        group = max(1, int(group))
+        ctx.group, ctx.M = group, M
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
         need_xe = need_xe and xe is not None
         need_b = need_b and b is not None
@@ -625,20 +660,23 @@ class _LinearCEFn(Function):
             ctx.param_refs = (W, b)
             ctx.unit_grads = (dx, dW, db)
             ctx.Kh, ctx.kx0 = Kh, kx0
-        picked = torch.empty(M, T, device=dev, dtype=torch.float32)
-        L.check(lib.dssvae_picked_logit(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b),
-                                        L.ptr(target), T, ctx.ignore, M, L.ptr(picked), L.stream()),
-                "dssvae_picked_logit")
+        # loss of every `group` consecutive rows (a sentence), gather + mask + sum in one launch
+        out = torch.empty((M + group - 1) // group, device=dev, dtype=torch.float32)
+        rows_nll = torch.empty(M, device=dev, dtype=torch.float32) if group > 1 else None
+        L.check(lib.dssvae_ce_finish(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), L.ptr(target), T,
+                                     ctx.ignore, L.ptr(lse), M, group, L.ptr(rows_nll), L.ptr(out), L.stream()),
+                "dssvae_ce_finish")
         if not ctx.fused:
             ctx.save_for_backward(xh, xe, W, b, target, lse, cnt)
-        return cnt * lse - picked.sum(1)
+        return out
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
             ctx.unit_grads = ctx.dWp = ctx.param_refs = None
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         need_xh, need_xe, need_w, need_b = ctx.needs_input_grad[:4]
+        group, M_rows = ctx.group, ctx.M
         if ctx.fused:
             # every row has the same upstream gradient (the caller's contract): scale the unit gradients
             if ctx.unit_grads is None:
@@ -651,7 +689,12 @@ class _LinearCEFn(Function):
                 raise RuntimeError("linear_ce(uniform_upstream=True): rows received different upstream gradients")
             dxh = dxe = None
             if dx is not None:
-                dx.mul_(g.unsqueeze(1))
+                if group == 1:
+                    dx.mul_(g.unsqueeze(1))
+                elif M_rows % group == 0:
+                    dx.view(M_rows // group, group, dx.size(1)).mul_(g.view(-1, 1, 1))
+                else:
+                    dx.mul_(g.repeat_interleave(group)[:M_rows].unsqueeze(1))
                 dxh = dx[:, :ctx.Kh] if need_xh else None  # kx0 == 0 whenever the h panel is wanted
                 dxe = dx[:, ctx.Kh - ctx.kx0:] if need_xe else None
             dWp, ctx.dWp = ctx.dWp, None
@@ -665,7 +708,7 @@ class _LinearCEFn(Function):
             if db is not None:
                 gb = _claim(b_ref)
                 db = torch.mul(db, c, out=gb) if gb is not None else (db * c if ctx.db_rides else db.mul_(c))
-            return dxh, dxe, dW, db, None, None, None
+            return dxh, dxe, dW, db, None, None, None, None
         # general path: per chunk of vocabulary columns, recompute dlogits into a
         # slab [M, nc] (+ the bias gradient by column sums in the same kernel), subtract the one-hot part,
         # then dX += dL.W_chunk (dgrad, accumulating) and dW_chunk = dL^T.[xh|xe] (wgrad, written once)
@@ -682,6 +725,8 @@ class _LinearCEFn(Function):
         M, N = xh.size(0), W.size(0)
         T = target.size(1)
         dev = xh.device
+        if group > 1:
+            g = g.repeat_interleave(group)[:M]
         g = g.contiguous()
         coef = (g * cnt).contiguous()
         g_mt = g.unsqueeze(1).expand(M, T).contiguous()
@@ -716,15 +761,17 @@ class _LinearCEFn(Function):
                 mm_tn(dlv, xcat, out=dW[n0:n1])
         dxh = dx[:, :Kh] if need_xh else None
         dxe = dx[:, Kh:] if need_xe else None
-        return dxh, dxe, dW, db, None, None, None
+        return dxh, dxe, dW, db, None, None, None, None
 
 
-def linear_ce(xh, xe, W, b, target, ignore_index=0, uniform_upstream=False):
-    """-> per-row summed NLL [M]; xe may be None; target [M] or [M,T].  uniform_upstream=True: the caller
+def linear_ce(xh, xe, W, b, target, ignore_index=0, uniform_upstream=False, group=1):
+    """-> per-row summed NLL [M] (group = 1) or the NLL of every `group` consecutive rows summed [ceil(M / group)]
+    (the rows of a sentence); xe may be None; target [M] or [M,T].  uniform_upstream=True: the caller
     guarantees that every row's NLL receives the same upstream gradient (see _LinearCEFn)."""
     # under no_grad nothing will ever ask for gradients: take the forward-only path (inside Function.forward
     # grad mode is always off and needs_input_grad still mirrors requires_grad, so decide here)
-    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index, bool(uniform_upstream) and torch.is_grad_enabled())
+    return _LinearCEFn.apply(xh, xe, W, b, target, ignore_index, bool(uniform_upstream) and torch.is_grad_enabled(),
+                             group)
 
 
 def linear_argmax(xh, xe, W, b):

@@ -34,7 +34,7 @@ class BridgeMLPMean(BridgeMLP):
         B = tgt_var.size(0)
         feat = self.bridger.forward(input_tensor=hidden).permute(1, 0, 2).contiguous().view(B, -1)
         if self.training and self.p > 0.0:
-            feat = feat * ops.dropout_mask(tuple(feat.shape), self.p, GLOBAL_SEEDS.next(), feat.device)
+            feat = ops.dropout(feat, self.p, GLOBAL_SEEDS.next())
         feat = self.scorer[2](self.scorer[1](feat))
         lin = self.scorer[3]
         return ops.linear_ce(feat, None, lin.weight, lin.bias, tgt_var, self.pad_id, uniform_upstream=uniform)

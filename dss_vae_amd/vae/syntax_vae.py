@@ -60,7 +60,7 @@ class BridgeMLP(nn.Module):
         B = tgt_var.size(0)
         feat = self.bridger.forward(input_tensor=hidden).permute(1, 0, 2).contiguous().view(B, -1)
         if self.training and self.p > 0.0:
-            feat = feat * ops.dropout_mask(tuple(feat.shape), self.p, GLOBAL_SEEDS.next(), feat.device)
+            feat = ops.dropout(feat, self.p, GLOBAL_SEEDS.next())
         lin = self.scorer[1]
         return ops.linear_ce(feat, None, lin.weight, lin.bias, tgt_var, self.pad_id, uniform_upstream=uniform)
 

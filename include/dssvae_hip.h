@@ -126,6 +126,19 @@ int dssvae_picked_logit(const float* Xh, int64_t ldh, int Kh, const float* Xe, i
                         const float* W, int64_t ldw, const float* bias, const int64_t* target, int T,
                         int64_t ignore_index, int M, float* picked, void* stream);
 
+/* Row weights and the loss itself, fused (each replaces three elementwise / reduction launches):
+ *   dssvae_ce_count : cnt[m] = number of targets of row m that are not ignore_index, as float
+ *   dssvae_ce_finish: out[s] = sum over rows m of sentence s (rows s*group .. s*group+group-1) and their targets t
+ *                     of (lse[m] - logit[m, target[m,t]]), ignored targets skipped -- the gather + mask + sum over
+ *                     time of RNNDecoder.score_decoding_results (decoder/rnn_decoder.py:96-103) and the NLLLoss sum
+ *                     of bag_of_word_loss (utils/loss_funcs.py:117-129); group = 1: per-row losses.  row_nll: [M]
+ *                     floats of scratch for the per-row losses (may be NULL when group = 1). */
+int dssvae_ce_count(const int64_t* target, int T, int64_t ignore_index, int M, float* cnt, void* stream);
+int dssvae_ce_finish(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                     const float* W, int64_t ldw, const float* bias, const int64_t* target, int T,
+                     int64_t ignore_index, const float* lse, int M, int group, float* row_nll, float* out,
+                     void* stream);
+
 /* Backward, one chunk of the vocabulary (the caller passes W, bias offset to the chunk's first
  * column and N = columns in the chunk; or all of it): dL[m,n] = coef[m] * exp(logit[m,n] - lse[m])
  * written to the caller's slab dL [M, ldd] (ldd >= N); colsum (may be NULL) [N] += sum_m dL[m,n]
@@ -157,6 +170,10 @@ int dssvae_embed_scatter_add(float* dtable, int64_t ldt, const int64_t* ids, int
 
 /* Bernoulli keep-mask scaled by 1/(1-p) (nn.Dropout semantics), counter-based RNG. */
 int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream);
+
+/* y = x * mask(seed) with the mask of dssvae_dropout_mask for the same (p, seed), without materialising it: the
+ * caller applies the same call to dy in backward (nn.Dropout between GRU layers, decoder/rnn_decoder.py:43). */
+int dssvae_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream);
 
 /* Word dropout: ids -> unk where rand < rate, never on sos/pad/eos (utils/nn_funcs.py:13-23).
  * `rand` NULL -> drawn on device from (seed). */

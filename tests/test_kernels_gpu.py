@@ -440,3 +440,32 @@ def test_adam_update_is_dropped_when_the_error_word_is_set():
     flag.zero_()
     ops.adam_step(p, g, m, v, 5e-4, 0.9, 0.995, 1e-8, 1, None, 0.0, flag)
     assert not torch.equal(p, before) and m.any()
+
+
+@pytest.mark.parametrize("uniform", [False, True])
+def test_linear_ce_sentence_groups_and_fused_dropout(uniform):
+    """group = T: the loss kernel sums the rows of a sentence itself -- same values and gradients as summing the
+    per-row losses; ops.dropout equals x * dropout_mask for the same seed, forward and backward"""
+    from dss_vae_amd import ops
+    B, T, Kh, Ke, N = 6, 5, 24, 8, 52
+    xh, xe = rnd(B * T, Kh, seed=1), rnd(B * T, Ke, seed=2)
+    W, b = rnd(N, Kh + Ke, seed=3, scale=0.3), rnd(N, seed=4)
+    tgt = torch.randint(0, N, (B * T,), generator=torch.Generator().manual_seed(5))
+    res = []
+    for group in (1, T):
+        leaves = [t.clone().to(DEV).requires_grad_(True) for t in (xh, xe, W, b)]
+        out = ops.linear_ce(leaves[0], leaves[1], leaves[2], leaves[3], tgt.to(DEV), 0, uniform_upstream=uniform,
+                            group=group)
+        sent = out.view(B, T).sum(1) if group == 1 else out
+        assert sent.shape == (B,)
+        (sent.sum() * 0.25).backward()
+        res.append((sent.detach().cpu(), [t.grad.detach().cpu() for t in leaves]))
+    close(res[1][0], res[0][0], rtol=1e-5, atol=1e-5, what="sentence sums")
+    for a, c in zip(res[1][1], res[0][1]):
+        close(a, c, rtol=1e-5, atol=1e-6, what="grad")
+    x = rnd(7, 33, seed=8).to(DEV).requires_grad_(True)
+    y = ops.dropout(x, 0.3, 1234)
+    m = ops.dropout_mask((7, 33), 0.3, 1234, DEV)
+    assert torch.equal(y, x.detach() * m)
+    y.backward(torch.ones_like(y))
+    assert torch.equal(x.grad, m)
