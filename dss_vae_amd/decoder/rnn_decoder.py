@@ -4,6 +4,8 @@ use_last_output=True).  Teacher-forced scoring never materialises [B,T,V] logits
 (ops.linear_ce); the per-step topk/.cpu() side work of rnn_decoder.py:132-144 is gone.
 ``score_many`` runs several decoders (main decoder + task heads) layer by layer so that their
 recurrences share persistent GRU launches."""
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -134,11 +136,77 @@ def prepare_job(job):
     return job
 
 
+# Measured and rejected as a default (round 2, same-box A/B at BASELINE configs[1]): 34.4 ms/step with the overlap
+# against 33.4 without.  The tails do run beside the projections (their launches take 2x as long there), but a
+# resident recurrence workgroup takes the place of one of the two GEMM workgroups of its CU, and the projections of
+# the main decoder lose more (LSE 110 -> 85 TFLOP/s, dgrad / wgrad -10 %) than the hidden recurrence steps were worth.
+OVERLAP_LONG_HEADS = os.environ.get("DSSVAE_OVERLAP", "0") == "1"
+
+
 def score_many(jobs):
     """jobs: dicts {dec, inputs [B,T+1], targets [B,T+1], h0 [layers,B,H], norm_by_word, no_grad, uniform}.
-    -> list of per-sentence log-probabilities [B], one per job.  All jobs advance layer by layer
-    together, so their recurrences share persistent GRU launches; a `no_grad` job (an adversary
-    that is only evaluated) is forward-only inside the shared launches."""
+    -> list of per-sentence log-probabilities [B], one per job.
+
+    Heads of very different lengths (the linearised-tree decoders run 3x the steps of the sentence heads) are cut
+    in time: steps [0, Ts) of EVERY head advance together in shared persistent launches on the current stream; the
+    remaining steps of the long heads -- a recurrence over a third of the chip, latency-bound -- continue from the
+    handed-over states on a side stream, BESIDE the vocabulary projections of the sentence heads (MFMA-bound).
+    Autograd replays every op on the stream of its forward, so backward overlaps the same way.  Persistent
+    launches themselves never overlap each other (ops._PersistentTurn)."""
+    jobs = list(jobs)
+    for j in jobs:
+        prepare_job(j)
+    steps = [j["inputs"].size(1) - 1 for j in jobs]
+    ts = min(steps)
+    long_ = [k for k, n in enumerate(steps) if n >= 2 * ts and n - ts >= 16]
+    if (not OVERLAP_LONG_HEADS or not long_ or len(long_) == len(jobs) or not jobs[0]["inputs"].is_cuda or
+            any(jobs[k].get("norm_by_word") for k in long_)):
+        return _score_group(jobs)[0]
+    # first part: every head, the long ones cut at ts (their embedding rows are split, not looked up again: the
+    # lookup is already on the autograd tape under the requires_grad flags of its moment)
+    first, tails = [], {}
+    for k, j in enumerate(jobs):
+        if k not in long_:
+            first.append(j)
+            continue
+        head = dict(j, inputs=j["inputs"][:, :ts + 1], targets=j["targets"][:, :ts + 1],
+                    _emb=j["_emb"][:, :ts].contiguous())
+        tails[k] = dict(j, inputs=j["inputs"][:, ts:], targets=j["targets"][:, ts:], _emb=j["_emb"][:, ts:].contiguous())
+        first.append(head)
+    xs, embs, states = _recur(first)
+    main = torch.cuda.current_stream()
+    side = ops._side_stream(jobs[0]["inputs"].device, 7)
+    side.wait_stream(main)  # i.e. for the recurrences above: the projections of this stream are enqueued below
+    tail_jobs = []
+    for k in long_:
+        t = tails[k]
+        t.pop("h0", None)
+        t["h0_layers"] = states[k]
+        for x in [t["_emb"], t["inputs"], t["targets"]] + list(states[k]):
+            x.record_stream(side)  # produced on this stream, read on the side stream
+        tail_jobs.append(t)
+    with torch.cuda.stream(side):
+        rest, _ = _score_group(tail_jobs)
+    res = _project(first, xs, embs)
+    main.wait_stream(side)
+    for k, r in zip(long_, rest):
+        r.record_stream(main)
+        res[k] = res[k] + r
+    return res
+
+
+def _score_group(jobs, want_states=False):
+    """recurrences, then projections, of one group of jobs on the current stream
+    -> (per-sentence log-probabilities, per job the list of final states per layer if want_states)"""
+    xs, embs, finals = _recur(jobs)
+    return _project(jobs, xs, embs), (finals if want_states else None)
+
+
+def _recur(jobs):
+    """All jobs advance layer by layer together, so their recurrences share persistent GRU launches; a `no_grad`
+    job (an adversary that is only evaluated) is forward-only inside the shared launches.  A job carries its initial
+    states as `h0` [layers,B,H] or as `h0_layers` (a list: the final states another group handed over).
+    -> (top-layer outputs per job, embedding rows per job, per job the list of final states per layer)"""
     n_layers = jobs[0]["dec"].n_layers
     assert all(j["dec"].n_layers == n_layers for j in jobs)
     grad_on = torch.is_grad_enabled()
@@ -149,7 +217,8 @@ def score_many(jobs):
         xs.append(e)
     # per-layer initial states: ONE unbind per head (its backward is one stack) instead of a select per layer
     # (whose backward is a zero-fill + copy per layer and an add to join them)
-    h0_layers = [j["h0"].unbind(0) for j in jobs]
+    h0_layers = [j["h0_layers"] if "h0_layers" in j else j["h0"].unbind(0) for j in jobs]
+    finals = [[] for _ in jobs]
     for layer in range(n_layers):
         insts, proj = [], {True: [], False: []}
         for k, j in enumerate(jobs):
@@ -171,7 +240,15 @@ def score_many(jobs):
                 with torch.set_grad_enabled(not ng):
                     for (k, _), xp in zip(items, ops.linear_many([t for _, t in items])):
                         insts[k]["xproj"] = xp
-        xs, _ = ops.gru_layer(insts)
+        xs, hl = ops.gru_layer(insts)
+        for k in range(len(jobs)):
+            finals[k].append(hl[k])
+    return xs, embs, finals
+
+
+def _project(jobs, xs, embs):
+    """fused vocabulary projection + cross-entropy of every job's top-layer outputs -> per-sentence log-probs"""
+    grad_on = torch.is_grad_enabled()
     res = []
     for k, j in enumerate(jobs):
         dec = j["dec"]

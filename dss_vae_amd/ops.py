@@ -228,11 +228,13 @@ _ONES_COL = {}
 def _ones_col(M, dev):
     """[M, 4] = (1, 0, 0, 0) per row: appended to the wgrad's right operand, the bias gradient comes out of the
     GEMM as one more output column"""
-    t = _ONES_COL.get(dev)
+    # one per stream: the fill is stream-ordered, another stream would read the column before it is written
+    key = (dev, torch.cuda.current_stream().cuda_stream)
+    t = _ONES_COL.get(key)
     if t is None or t.size(0) < M:
         t = torch.zeros(max(M, 8192), 4, device=dev, dtype=torch.float32)
         t[:, 0] = 1.0
-        _ONES_COL[dev] = t
+        _ONES_COL[key] = t
     return t[:M]
 
 
@@ -891,14 +893,47 @@ def persistent_error_word(device):
         key = torch.cuda.current_device()
     if key not in _PERSISTENT_ERR:
         _PERSISTENT_ERR[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
+        torch.cuda.current_stream().synchronize()  # once: every stream may use the word from now on
     return _PERSISTENT_ERR[key]
+
+
+_ZERO_IDX = {}
 
 
 def _note_persistent_error(wsb):
     """fold the launch's error word (first int32 of its workspace: a bounded spin gave up) into a sticky
     per-device counter, on the stream and without a host sync; `check_persistent_errors` reads it, and the
-    optimiser's update kernel reads it on device (a timed-out step never reaches the parameters)."""
-    persistent_error_word(wsb.device).add_(wsb[:4].view(torch.int32))
+    optimiser's update kernel reads it on device (a timed-out step never reaches the parameters).  The add is
+    atomic (index_add_): persistent launches of different streams may report at the same time."""
+    dev = wsb.device
+    if dev not in _ZERO_IDX:
+        _ZERO_IDX[dev] = torch.zeros(1, device=dev, dtype=torch.int64)
+        torch.cuda.current_stream().synchronize()  # once: every stream may use it from now on
+    persistent_error_word(dev).index_add_(0, _ZERO_IDX[dev], wsb[:4].view(torch.int32))
+
+
+# Persistent launches never overlap EACH OTHER, whatever streams they are on: two partly resident grids can starve
+# one another of the CUs (LDS) the rest of their workgroups need, and each would spin until its limit.  Every
+# persistent launch waits for the previous one's completion event and leaves its own (GEMMs and the other kernels
+# of other streams still run beside a recurrence: that overlap is what the streams are for).
+_PERSISTENT_DONE = {}
+
+
+class _PersistentTurn(object):
+    def __init__(self, dev):
+        self.key = torch.device(dev).index if torch.device(dev).index is not None else torch.cuda.current_device()
+
+    def __enter__(self):
+        prev = _PERSISTENT_DONE.get(self.key)
+        if prev is not None:
+            torch.cuda.current_stream().wait_event(prev)
+        return self
+
+    def __exit__(self, *exc):
+        ev = torch.cuda.Event()
+        ev.record()
+        _PERSISTENT_DONE[self.key] = ev
+        return False
 
 
 def check_persistent_errors():
@@ -978,8 +1013,8 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save[i] else 4) for i in launch)
-            with _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch),
-                       detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
+            with _PersistentTurn(dev), _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch),
+                                             detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
                 L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
             _note_persistent_error(wsb)
             if meta.get("check"):
@@ -1051,8 +1086,8 @@ class _GruFn(Function):
             wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
             fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
             by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
-            with _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch),
-                       detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
+            with _PersistentTurn(dev), _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch),
+                                             detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
                 L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
             _note_persistent_error(wsb)
             if meta.get("check"):

@@ -11,6 +11,7 @@ into ONE flat gradient buffer, so that
     (no host sync in the step).
 """
 import os
+import warnings
 
 import torch
 
@@ -27,6 +28,11 @@ def build_model_params_(model, seed=None, bound=0.08):
         for p in model.parameters():
             p.copy_(torch.empty(p.shape).uniform_(-bound, bound, generator=g).to(p.device))
     return model
+
+
+# heads that run on a side stream (decoder/rnn_decoder.py: score_many) hand their parameter gradients to
+# AccumulateGrad nodes of the default stream: the engine orders the two streams itself and says so once per run
+warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
 
 
 class FlatAdam(object):
