@@ -113,7 +113,41 @@ def cpu_baseline(a, margs_dict):
             "s_per_step": med}
 
 
-def generate_bench(a, model, vocab, margs, rank, world):
+def cpu_generate_baseline(a, margs_dict, n_batches=12):
+    """the oracle's prior sampling + greedy decode (kind "port": base_vae.py:69-85 through the CPU restatement) on the
+    host cores, a bounded sample of the same workload: n_batches batches of eval_bs sentences, 1 warm-up batch"""
+    import copy
+    from argparse import Namespace
+    import torch
+    import oracle
+    threads = torch.get_num_threads()
+    src, tgt = oracle.OVocabEntry(), oracle.OVocabEntry()
+    for i in range(a.vocab - 4):
+        src.add("w%d" % i)
+    for i in range(a.tree_vocab - 4):
+        tgt.add("t%d" % i)
+    om = oracle.ORACLE_MODELS[a.model](Namespace(**copy.deepcopy(margs_dict)), oracle.OVocab(src, tgt))
+    oracle.init_uniform_(om, seed=0)
+    om.eval()
+    bs = a.gen_batch
+
+    def one():
+        with torch.no_grad():
+            return om.decode_to_sentence(om.latent_for_init(om.sample_latent(bs)))[0]
+
+    one()
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(n_batches):
+        n += len(one())
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "sentences/s", "cores": threads, "kind": "port",
+            "sample": "%d batches of %d prior samples, greedy decode of %d steps, tokens to words (CPU oracle, torch %s, "
+                      "%d threads), after 1 warm-up batch" % (n_batches, bs, margs_dict["src_max_time_step"],
+                                                              torch.__version__, threads)}
+
+
+def generate_bench(a, model, vocab, margs, rank, world, margs_dict=None):
     """BASELINE configs[4]: decoder-only generation.  (1) prior sampling: `generating(n, eval_bs)`
     (base_vae.py:69-85), always max_len = 35 greedy steps, tokens -> words on the host as the reference
     does; (2) syntax transfer: `eval_adv(sem_in, syn_ref)` (enhance_syntax_vae.py:485-497) = two encodes,
@@ -126,13 +160,38 @@ def generate_bench(a, model, vocab, margs, rank, world):
     torch.manual_seed(7 + rank)
     out = {}
     with torch.no_grad():
+        import ctypes as C
+        from dss_vae_amd import lib as L
+        lib = L.load()
         model.generating(bs, bs)  # warm-up
         torch.cuda.synchronize()
+        lib.dssvae_decode_profile(0 if a.no_kernel_events else 1)  # HIP events around every projection + arg-max launch
         t0 = time.perf_counter()
         res = model.generating(n, bs)
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        tot_ms, launches = C.c_double(0.0), C.c_int(0)
+        L.check(lib.dssvae_decode_profile_read(C.byref(tot_ms), C.byref(launches)), "dssvae_decode_profile_read")
+        lib.dssvae_decode_profile(0)
         out["prior_sampling"] = {"sentences": len(res), "seconds": dt, "sentences_per_s": len(res) / dt}
+        if launches.value:
+            # dominant kernel of the loop: [h ; e] W_out^T fused with the arg-max.  Algorithmic bytes per launch: W_out
+            # once (4 V (H + E)); the activations and partials are noise beside it.  MFMA work per launch: the decode
+            # batch padded to the kernel's 32-row groups.
+            dec = model.decoder
+            H, E, V = dec.hidden_size, dec.input_size, dec.vocab_size
+            avg_ms = tot_ms.value / launches.value
+            nbytes = 4.0 * V * (H + E)
+            rows = (bs + 31) // 32 * 32
+            flops = 2.0 * rows * V * (H + E)
+            gbs = nbytes / (avg_ms * 1e-3) / 1e9
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "skinny_kernel<ARGMAX>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
+                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
+                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e3 * avg_ms,
+                               "launches": launches.value, "share_of_wall": tot_ms.value * 1e-3 / dt,
+                               "mfma": {"flops_per_launch_padded_rows": flops, "tflops": tf,
+                                        "frac": tf / PEAK_F32_MFMA_TFLOPS, "rows": rows}}
         if a.model == "SyntaxVAE2":
             exs = synthetic.examples(bs, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len, fixed=False,
                                      seed=99 + rank)
@@ -155,6 +214,8 @@ def generate_bench(a, model, vocab, margs, rank, world):
                                                                          a.vocab)}}
     line.update(out)
     if rank == 0:
+        if not a.no_cpu_baseline and world == 1 and margs_dict is not None:
+            line["cpu_baseline"] = cpu_generate_baseline(a, margs_dict)
         print(json.dumps(line), flush=True)
 
 
@@ -208,7 +269,7 @@ def main():
     n_params = sum(p.numel() for p in model.parameters())
     opt = FlatAdam(model, lr=0.0005, betas=(0.9, 0.995), clip_grad=5.0)
     if a.mode == "generate":
-        return generate_bench(a, model, vocab, margs, rank, world)
+        return generate_bench(a, model, vocab, margs, rank, world, margs_dict)
     exs = synthetic.examples(a.batch, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len,
                              fixed=not a.variable_lengths, seed=1234 + rank)
     batch = DeviceBatch(exs, vocab)

@@ -7,6 +7,7 @@
 // reference does a topk + .cpu() per step), so the whole decode is also capturable in a HIP graph.
 #include "common.h"
 #include <mutex>
+#include <vector>
 
 // Scratch of the no-allocation entry point (dssvae_greedy_decode_noalloc): the loop's whole workspace lives in
 // this file-scope device array, one copy per GPU, held until the process ends.  In host code the array's NAME is
@@ -36,6 +37,24 @@ int scratch_address(void** out) {
     }
     *out = g_scratch_ptr[dev];
     return DSSVAE_OK;
+}
+
+// Optional live timing of the loop's dominant launch (projection + arg-max over the vocabulary): while armed,
+// every such launch is bracketed by two HIP events on the launch stream (bench.py reads the sum afterwards).
+struct ArgmaxProfile {
+    std::vector<hipEvent_t> ev;  // pairs
+    size_t used = 0;
+    bool on = false;
+} g_prof;
+
+inline void prof_mark(hipStream_t s) {
+    if (!g_prof.on) return;
+    if (g_prof.used == g_prof.ev.size()) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) { g_prof.on = false; return; }
+        g_prof.ev.push_back(e);
+    }
+    (void)hipEventRecord(g_prof.ev[g_prof.used++], s);
 }
 
 struct Ws {
@@ -167,6 +186,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
             in_dim = H;
         }
         int S = dssvae_skinny_argmax_splits(B, V);
+        prof_mark(s);
         rc = dssvae_skinny_argmax(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, w.pmax, w.psum, w.parg,
                                   stream);
         if (rc == DSSVAE_ETOOBIG) {
@@ -174,6 +194,7 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
             rc = dssvae_linear_lse_fwd(in, H, H, w.x, E, E, p->w_out, p->ld_out, p->b_out, B, V, n_split, w.pmax,
                                        w.psum, w.parg, 1, nullptr, 0, stream);
         }
+        prof_mark(s);
         if (rc != DSSVAE_OK) return rc;
         hipLaunchKernelGGL(combine_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pmax, w.parg, B, S,
                            tokens + (size_t)t * B, p->embedding, p->ld_embedding, E, w.x);
@@ -206,4 +227,31 @@ extern "C" int dssvae_greedy_decode_noalloc(const dssvae_decode_params* p, const
     const int rc = scratch_address(&ptr);
     if (rc != DSSVAE_OK) return rc;
     return dssvae_greedy_decode(p, h0, B, max_len, sos_id, n_split, tokens, h_final, ptr, need, stream);
+}
+
+// Measurement hooks (no reference counterpart): arm = 1 starts bracketing every projection + arg-max launch of the
+// greedy loops with HIP events on their stream (and forgets earlier spans), arm = 0 stops.  dssvae_decode_profile_read
+// waits for the recorded events and returns the summed duration and the number of launches.
+extern "C" int dssvae_decode_profile(int arm) {
+    g_prof.used = 0;
+    g_prof.on = arm != 0;
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_decode_profile_read(double* total_ms_host, int* launches_host) {
+    if (!total_ms_host || !launches_host) return DSSVAE_EINVAL;
+    double tot = 0.0;
+    int n = 0;
+    for (size_t i = 0; i + 1 < g_prof.used; i += 2) {
+        hipError_t e = hipEventSynchronize(g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        float ms = 0.f;
+        e = hipEventElapsedTime(&ms, g_prof.ev[i], g_prof.ev[i + 1]);
+        if (e != hipSuccess) return (int)e;
+        tot += ms;
+        ++n;
+    }
+    *total_ms_host = tot;
+    *launches_host = n;
+    return DSSVAE_OK;
 }

@@ -100,6 +100,8 @@ _SIGNATURES = {
     "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
     "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),
     "dssvae_greedy_decode_noalloc": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P], _I),
+    "dssvae_decode_profile": ([_I], _I),
+    "dssvae_decode_profile_read": ([C.POINTER(C.c_double), C.POINTER(C.c_int)], _I),
     "dssvae_sumsq": ([_P, _L, _P, _P, _P], _I),
     "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P, _P], _I),
 }

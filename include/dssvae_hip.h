@@ -327,6 +327,12 @@ int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, 
 int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, int B, int max_len,
                          int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
                          int64_t workspace_bytes, void* stream);
+/* Live timing of the loop's dominant launch (projection + arg-max over the vocabulary) for the roofline report: arm
+ * = 1 brackets every such launch with HIP events on the launch stream, arm = 0 stops; _read waits for the events and
+ * returns their summed duration and count.  No reference counterpart (measurement only; not thread-safe). */
+int dssvae_decode_profile(int arm);
+int dssvae_decode_profile_read(double* total_ms_host, int* launches_host);
+
 /* dssvae_greedy_decode without a workspace argument and without any allocation.  NO COUNTERPART IN THE
  * REFERENCE: it exists for callers that cannot call hipMalloc (code under HIP graph capture, tight serving
  * loops, harnesses that forbid allocation).  The loop's workspace is a file-scope device array inside the
