@@ -109,7 +109,9 @@ def cpu_baseline(a, margs_dict):
     med = ts[len(ts) // 2]
     return {"value": a.cpu_batch / med, "unit": "sentences/s", "cores": threads, "kind": "port",
             "sample": "%d timed steps (median) after 1 warm-up of the same model/config at batch %d "
-                      "(CPU oracle, torch %s, %d threads)" % (a.cpu_steps, a.cpu_batch, torch.__version__, threads),
+                      "(CPU oracle, torch %s, %d threads; the oracle skips the reference's per-timestep topk + .cpu() "
+                      "side work -- 275 calls per pass -- so the reference itself is a little slower than this)"
+                      % (a.cpu_steps, a.cpu_batch, torch.__version__, threads),
             "s_per_step": med}
 
 
@@ -346,6 +348,8 @@ def main():
                                 "algorithmic_per_launch": (d["flops"] if bound == "mfma" else d["bytes"]) / d["launches"],
                                 "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                 "tflops": d["flops"] / (d["total_ms"] * 1e-3) / 1e12,
+                                "mfma_frac": d["flops"] / (d["total_ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                "hbm_frac": d["bytes"] / (d["total_ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                 "us_per_timestep": (1e3 * d["total_ms"] / d["timesteps"]) if d.get("timesteps") else None,
                                 "launches_per_step": d["launches"] / a.steps,
                                 "avg_launch_ms": d["avg_ms"], "ms_per_step": d["total_ms"] / a.steps})

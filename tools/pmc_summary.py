@@ -18,7 +18,8 @@ NAMES = ["gemm_store_kernel", "gemm_group_kernel", "dssvae_zero2d_kernel", "line
          "adam_kernel", "sumsq_kernel", "softmax_grad_kernel", "colsum_kernel", "lse_combine_kernel",
          "picked_logit_kernel", "onehot_sub_kernel", "embed_scatter_kernel", "embed_gather_kernel",
          "reparam_kl_fwd_kernel", "reparam_kl_bwd_kernel", "greedy_decode_kernel", "skinny_kernel<true", "skinny_kernel<false",
-         "skinny_gru_kernel", "combine_gather_kernel"]
+         "skinny_gru_kernel", "combine_gather_kernel", "ce_rowinfo_kernel", "ce_onehot_fixup_kernel", "ce_count_kernel",
+         "ce_row_nll_kernel", "ce_group_sum_kernel", "dropout_apply_kernel", "dssvae_zero_many_kernel"]
 PAT = re.compile("|".join(NAMES))
 csv.field_size_limit(1 << 30)
 
@@ -51,6 +52,11 @@ def main():
     for kern, k in res.items():
         if "FETCH_SIZE" in k and "WRITE_SIZE" in k:
             k["hbm_bytes_per_launch"] = (2.0 * k["FETCH_SIZE"] + k["WRITE_SIZE"]) * 1024.0
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in k and k.get("SQ_BUSY_CU_CYCLES"):
+            # matrix-pipe utilisation while the kernel has CUs busy (4 SIMDs per CU); share of wave cycles spent waiting
+            k["mfma_pipe_utilisation"] = k["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * k["SQ_BUSY_CU_CYCLES"])
+        if "SQ_WAIT_INST_ANY" in k and k.get("SQ_WAVE_CYCLES"):
+            k["wave_cycles_waiting"] = k["SQ_WAIT_INST_ANY"] / k["SQ_WAVE_CYCLES"]
     with open(out_path, "w") as fh:
         json.dump(res, fh, indent=1, sort_keys=True)
     for kern in sorted(res):

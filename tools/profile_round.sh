@@ -18,5 +18,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python $ROOT/tools/pmc_summary.py $OUT/${TAG}_pmc_traffic.json FETCH_SIZE=$OUT/${TAG}_pmc_FETCH_SIZE WRITE_SIZE=$OUT/${TAG}_pmc_WRITE_SIZE > $OUT/${TAG}_pmc_traffic.txt
 rm -rf $OUT/${TAG}_pmc_FETCH_SIZE $OUT/${TAG}_pmc_WRITE_SIZE
+# SQ counters per kernel (its own pass): matrix-pipe utilisation and wait share, the recurrences included
+timeout -s KILL 240 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/${TAG}_pmc_SQ -o p -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kernel-events > /dev/null 2>&1 || exit 1
+python $ROOT/tools/pmc_summary.py $OUT/${TAG}_sq_counters.json SQ=$OUT/${TAG}_pmc_SQ > $OUT/${TAG}_sq_counters.txt
+rm -rf $OUT/${TAG}_pmc_SQ
 cut -c1-300 $OUT/${TAG}_bench.json
 head -12 $OUT/${TAG}_gaps.txt
