@@ -73,6 +73,7 @@ struct Stager {
     float s[VEC ? 1 : NS];
     float ri[XF ? NV : 1];    // l2 of the slab rows of the staged granules (XF)
     const float* xf;
+    bool xf_vec;              // xf is 16-byte aligned
     const float* b1[(!TRANS && VEC) ? NV : 1];
     const float* b2[(!TRANS && VEC) ? NV : 1];
     const float* p1; const float* p2; const int64_t* rows;
@@ -83,6 +84,7 @@ struct Stager {
     __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int K1_, const float* p2_, int64_t ld2_,
                                          const int64_t* rows_, int Rtot_, int r0_, int K_, const float* xf_ = nullptr) {
         xf = xf_;
+        xf_vec = (reinterpret_cast<uintptr_t>(xf_) & 15u) == 0;
         p1 = p1_; ld1 = ld1_; K1 = K1_; p2 = p2_ ? p2_ : p1_; ld2 = p2_ ? ld2_ : ld1_; rows = rows_;
         Rtot = Rtot_; r0 = r0_; K = K_;
         if (!TRANS && VEC) {
@@ -95,6 +97,13 @@ struct Stager {
                 if (XF) ri[i] = xf[r];   // the slab rows of this thread's granules never change
             }
         }
+    }
+
+    // TRANS, VEC: k row (inside the tile) of this thread's granule i.  XF: 4 consecutive rows per thread (their row
+    // records are one 16-byte load); else rows KSTEP apart (neighbouring threads of a pass share a row either way)
+    static __device__ __forceinline__ int krow(int i) {
+        constexpr int TPK = R / (VEC ? VW : 1), KSTEP = NTHREADS / TPK;
+        return XF ? NV * (int)(threadIdx.x / TPK) + i : (int)(threadIdx.x / TPK) + KSTEP * i;
     }
 
     // softmax part of dlogits for one granule of a slab row: two VALU instructions per element (v_fma, v_exp)
@@ -151,14 +160,28 @@ struct Stager {
                 constexpr int TPK = R / VW;          // threads per k row
                 constexpr int KSTEP = NTHREADS / TPK;
                 const int rv = min(r0 + VW * (int)(threadIdx.x % TPK), Rtot - VW);
+                if constexpr (XF) {
+                    // the slab rows' l2 values: this thread's NV granules sit in CONSECUTIVE slab rows (krow), so
+                    // they are one 16-byte load per k-tile instead of one dword load per granule
+                    static_assert(NV == 4 && KSTEP * NV == BK, "row record load assumes 4 consecutive rows per thread");
+                    if (part == 0) {
+                        const int kb = lk0 + NV * (int)(threadIdx.x / TPK);
+                        if (kb + NV <= K && xf_vec) {
+                            const float4 q = *reinterpret_cast<const float4*>(xf + kb);
+                            ri[0] = q.x; ri[1] = q.y; ri[2] = q.z; ri[3] = q.w;
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < NV; ++i) ri[i] = xf[min(kb + i, K - 1)];
+                        }
+                    }
+                }
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (in_part(i, part)) {
-                        const int k = lk0 + (int)(threadIdx.x / TPK) + KSTEP * i;
+                        const int k = lk0 + krow(i);
                         const bool ok = k < K;
                         okmask |= ok ? (1u << i) : 0u;
                         v[i] = *reinterpret_cast<const V*>(p1 + (int64_t)(ok ? k : 0) * ld1 + rv);
-                        if (XF) ri[i] = xf[ok ? k : 0];
                     }
             } else {
                 constexpr int KSTEP = NTHREADS / R;  // R = 64 -> 4, R = 128 -> 2
@@ -209,12 +232,11 @@ struct Stager {
         } else {
             if (VEC) {
                 constexpr int TPK = R / VW;
-                constexpr int KSTEP = NTHREADS / TPK;
 #pragma unroll
                 for (int i = 0; i < NV; ++i)
                     if (in_part(i, part)) {
                         const V val = v[i];
-                        *reinterpret_cast<V*>(img + ((threadIdx.x / TPK) + KSTEP * i) * (R + 4) + VW * (threadIdx.x % TPK)) =
+                        *reinterpret_cast<V*>(img + krow(i) * (R + 4) + VW * (threadIdx.x % TPK)) =
                             ((okmask >> i) & 1u) ? val : VecT<VW>::zero();
                     }
             } else {
