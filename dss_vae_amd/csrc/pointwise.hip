@@ -154,6 +154,69 @@ __global__ void gru_step_bwd_kernel(const float* __restrict__ gates, int64_t g_r
     dhz[i] = g * z;
 }
 
+// ---- LSTM (nn.LSTM gate order i, f, g, o), stepwise: the recurrent product gh = h_{t-1} W_hh^T comes from the GEMM,
+// these fuse the cell of ONE timestep.  Saved history row (for backward): [i | f | g | o | c_{t-1} | h_{t-1} | tanh c_t].
+__global__ void lstm_step_fwd_kernel(const float* __restrict__ x, int64_t x_rs, const float* __restrict__ gh,
+                                     const float* __restrict__ bhh, const float* __restrict__ h,
+                                     const float* __restrict__ c, const int32_t* __restrict__ lengths, int t, int B,
+                                     int H, float* __restrict__ hn, float* __restrict__ cn, float* __restrict__ out,
+                                     int64_t out_rs, float* __restrict__ gates, int64_t g_rs) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int64_t b = idx / H, u = idx % H;
+    const float* a = x + b * x_rs;
+    const float* r = gh + b * 4 * H;
+    const float hp = h ? h[idx] : 0.f, cp = c ? c[idx] : 0.f;
+    const float gi = sigmoidf_(a[u] + r[u] + bhh[u]);
+    const float gf = sigmoidf_(a[H + u] + r[H + u] + bhh[H + u]);
+    const float gg = tanhf(a[2 * H + u] + r[2 * H + u] + bhh[2 * H + u]);
+    const float go = sigmoidf_(a[3 * H + u] + r[3 * H + u] + bhh[3 * H + u]);
+    const float cv = gf * cp + gi * gg;
+    const float tc = tanhf(cv);
+    const float hv = go * tc;
+    const bool live = !lengths || t < lengths[b];
+    hn[idx] = live ? hv : hp;
+    cn[idx] = live ? cv : cp;
+    if (out) out[b * out_rs + u] = live ? hv : 0.f;
+    if (gates) {
+        float* g = gates + b * g_rs;
+        g[u] = gi; g[H + u] = gf; g[2 * H + u] = gg; g[3 * H + u] = go; g[4 * H + u] = cp; g[5 * H + u] = hp;
+        g[6 * H + u] = tc;
+    }
+}
+
+// Backward of one timestep: dh, dc (gradients wrt h_t, c_t from the future) + dout_t -> dg_t [4H] (the gradient wrt the
+// gate pre-activations: the same for the input and the recurrent product), dhz = 0-part of dh_{t-1} that bypasses W_hh
+// (only for rows past their length), dc_{t-1}.  The caller adds dg_t W_hh to dhz.
+__global__ void lstm_step_bwd_kernel(const float* __restrict__ gates, int64_t g_rs, const float* __restrict__ dout,
+                                     int64_t d_rs, const float* __restrict__ dh, const float* __restrict__ dc,
+                                     const int32_t* __restrict__ lengths, int t, int B, int H,
+                                     float* __restrict__ dg, int64_t o_rs, float* __restrict__ dhz,
+                                     float* __restrict__ dcp) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * H) return;
+    const int64_t b = idx / H, u = idx % H;
+    const float gin = dh ? dh[idx] : 0.f, cin = dc ? dc[idx] : 0.f;
+    float* o = dg + b * o_rs;
+    const bool live = !lengths || t < lengths[b];
+    if (!live) {
+        o[u] = o[H + u] = o[2 * H + u] = o[3 * H + u] = 0.f;
+        dhz[idx] = gin;
+        dcp[idx] = cin;
+        return;
+    }
+    const float* gs = gates + b * g_rs;
+    const float gi = gs[u], gf = gs[H + u], gg = gs[2 * H + u], go = gs[3 * H + u], cp = gs[4 * H + u], tc = gs[6 * H + u];
+    const float g = gin + (dout ? dout[b * d_rs + u] : 0.f);
+    const float dct = cin + g * go * (1.f - tc * tc);
+    o[u] = dct * gg * gi * (1.f - gi);
+    o[H + u] = dct * cp * gf * (1.f - gf);
+    o[2 * H + u] = dct * gi * (1.f - gg * gg);
+    o[3 * H + u] = g * tc * go * (1.f - go);
+    dhz[idx] = 0.f;
+    dcp[idx] = dct * gf;
+}
+
 // Sum of squares in a FIXED order (block partials -> one block adds them up): data-parallel replicas must
 // compute bit-identical clip coefficients from bit-identical averaged gradients, which float atomics in
 // arrival order do not give.
@@ -322,6 +385,35 @@ extern "C" int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_strid
     hipLaunchKernelGGL(gru_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        gates_t, gates_row_stride, dout_t, dout_row_stride, dh, lengths, t, B, H, dgx_t, dgh_t,
                        dg_row_stride, dhz);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_lstm_step_fwd(const float* x_t, int64_t x_row_stride, const float* gh, const float* bhh,
+                                    const float* h_prev, const float* c_prev, const int32_t* lengths, int t, int B,
+                                    int H, float* h_new, float* c_new, float* out_t, int64_t out_row_stride,
+                                    float* gates_t, int64_t gates_row_stride, void* stream) {
+    if (!x_t || !gh || !bhh || !h_new || !c_new || B <= 0 || H <= 0 || x_row_stride < 4 * H) return DSSVAE_EINVAL;
+    if ((out_t && out_row_stride < H) || (gates_t && gates_row_stride < 7 * H)) return DSSVAE_EINVAL;
+    const int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(lstm_step_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x_t,
+                       x_row_stride, gh, bhh, h_prev, c_prev, lengths, t, B, H, h_new, c_new, out_t, out_row_stride,
+                       gates_t, gates_row_stride);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_lstm_step_bwd(const float* gates_t, int64_t gates_row_stride, const float* dout_t,
+                                    int64_t dout_row_stride, const float* dh, const float* dc, const int32_t* lengths,
+                                    int t, int B, int H, float* dg_t, int64_t dg_row_stride, float* dhz, float* dc_prev,
+                                    void* stream) {
+    if (!gates_t || !dg_t || !dhz || !dc_prev || B <= 0 || H <= 0 || gates_row_stride < 7 * H ||
+        dg_row_stride < 4 * H || (dout_t && dout_row_stride < H))
+        return DSSVAE_EINVAL;
+    const int64_t n = (int64_t)B * H;
+    hipLaunchKernelGGL(lstm_step_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       gates_t, gates_row_stride, dout_t, dout_row_stride, dh, dc, lengths, t, B, H, dg_t,
+                       dg_row_stride, dhz, dc_prev);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

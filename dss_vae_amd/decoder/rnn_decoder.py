@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from ..networks.embeddings import lookup
-from ..networks.rnn_base import GLOBAL_SEEDS, GRUParams, RNNBase
+from ..networks.rnn_base import GLOBAL_SEEDS, RNNBase
 
 
 class RNNDecoder(RNNBase):
@@ -28,7 +28,7 @@ class RNNDecoder(RNNBase):
         if use_attention or not use_last_output:
             raise NotImplementedError("the VAE hot path forces use_attention=False (vae/enhance_syntax_vae.py:71) "
                                       "and use_last_output=True")
-        self.rnn = GRUParams(input_size, hidden_size, n_layers, dropout=rnn_droprate)
+        self.rnn = self.make_rnn(input_size, hidden_size, n_layers, dropout=rnn_droprate)
         self.max_length = max_len
         self.use_attention, self.use_last_output = False, True
         self.eos_id, self.sos_id, self.pad_id = eos_id, sos_id, pad_id
@@ -42,6 +42,14 @@ class RNNDecoder(RNNBase):
     def score_inputs(self, inputs, targets, encoder_hidden, norm_by_word=False, uniform=False):
         """log p(targets[:,1:] | inputs[:,:-1], h0) per sentence, [B].  uniform=True: the caller only
         ever sums the result with one common weight (see ops._LinearCEFn)."""
+        if self.is_lstm:
+            out, emb, _ = self._features(inputs[:, :-1].contiguous(), encoder_hidden)
+            B, T, H = out.shape
+            logp = -ops.linear_ce(out.reshape(B * T, H), emb.reshape(B * T, -1), self.out.weight, self.out.bias,
+                                  targets[:, 1:].reshape(-1), self.pad_id, uniform_upstream=uniform, group=T)
+            if norm_by_word:
+                logp = logp.div(targets.ne(self.pad_id).sum(dim=-1).float())
+            return logp
         return score_many([dict(dec=self, inputs=inputs, targets=targets, h0=encoder_hidden,
                                 norm_by_word=norm_by_word, uniform=uniform)])[0]
 
@@ -51,6 +59,19 @@ class RNNDecoder(RNNBase):
     # ---- compatibility: materialised logits (not used by the model hot path) -------------------
     def _features(self, ids, h0):
         emb = lookup(self.embedding, ids, GLOBAL_SEEDS)
+        if self.is_lstm:
+            # hidden is nn.LSTM's (h_0, c_0), each [layers,B,H] (decoder/rnn_decoder.py:65 with rnn_cell='lstm')
+            h0s, c0s = h0
+            x, hl, cl = emb, [], []
+            for layer in range(self.n_layers):
+                if layer > 0 and self.training and self.rnn_droprate > 0.0:
+                    x = ops.dropout(x, self.rnn_droprate, GLOBAL_SEEDS.next())
+                wih, whh, bih, bhh = self.rnn.layer_params(layer)
+                x, h, c = ops.lstm_layer(ops.linear(x, wih, bih.detach()), whh, bhh, h0=h0s[layer], c0=c0s[layer],
+                                         bih=bih)
+                hl.append(h)
+                cl.append(c)
+            return x, emb, (torch.stack(hl, 0), torch.stack(cl, 0))
         x, hl = emb, []
         for layer in range(self.n_layers):
             if layer > 0 and self.training and self.rnn_droprate > 0.0:
@@ -90,9 +111,30 @@ class RNNDecoder(RNNBase):
         The whole loop is one native call: per step embedding rows, 2 small GEMMs + fused cell per
         layer, projection fused with the arg-max; no host round trip per step."""
         max_length = self.max_length if max_length is None else max_length
+        if self.is_lstm:
+            return self._greedy_lstm(encoder_hidden, max_length)
         params = [self.rnn.layer_params(l) for l in range(self.n_layers)]
         return ops.greedy_decode(self.embedding.weight, params, self.out.weight, self.out.bias, encoder_hidden,
                                  self.sos_id, max_length)
+
+    def _greedy_lstm(self, hidden, max_length):
+        """the greedy loop for the LSTM cell: per step and layer two MFMA products + the fused cell kernel, then the
+        projection fused with the arg-max; enqueued step by step from the host (no device->host traffic), not the
+        one-call native loop of the GRU"""
+        h, c = [t.contiguous() for t in hidden[0].unbind(0)], [t.contiguous() for t in hidden[1].unbind(0)]
+        B = h[0].size(0)
+        tok = torch.full((B,), self.sos_id, device=h[0].device, dtype=torch.int64)
+        params = [self.rnn.layer_params(l) for l in range(self.n_layers)]
+        seq = []
+        for _ in range(max_length):
+            emb = ops.embed(self.embedding.weight, tok, None)
+            x = emb
+            for l, (wih, whh, bih, bhh) in enumerate(params):
+                h[l], c[l] = ops.lstm_cell(ops.mm_nt(x, wih, bih), ops.mm_nt(h[l], whh, bhh), c[l])
+                x = h[l]
+            tok = ops.linear_argmax(x, emb, self.out.weight, self.out.bias)
+            seq.append(tok)
+        return torch.stack(seq, 0), (torch.stack(h, 0), torch.stack(c, 0))
 
     def forward(self, inputs=None, encoder_hidden=None, encoder_outputs=None, function=F.log_softmax,
                 teacher_forcing_ratio=0.0):

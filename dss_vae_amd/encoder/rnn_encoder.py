@@ -6,7 +6,7 @@ import torch
 
 from .. import ops
 from ..networks.embeddings import lookup
-from ..networks.rnn_base import GLOBAL_SEEDS, GRUParams, RNNBase
+from ..networks.rnn_base import GLOBAL_SEEDS, RNNBase
 
 
 class RNNEncoder(RNNBase):
@@ -19,7 +19,7 @@ class RNNEncoder(RNNBase):
         if embedding is not None:
             self.embedding = embedding
         self.embedding.weight.requires_grad = update_embedding
-        self.rnn = GRUParams(input_size, hidden_size, n_layers, bidirectional=bidirectional, dropout=rnn_droprate)
+        self.rnn = self.make_rnn(input_size, hidden_size, n_layers, bidirectional=bidirectional, dropout=rnn_droprate)
         self.bidirectional = bidirectional
 
     @property
@@ -27,7 +27,34 @@ class RNNEncoder(RNNBase):
         return self.hidden_size * 2 if self.bidirectional else self.hidden_size
 
     def forward(self, input_var, input_lengths=None):
+        if self.is_lstm:
+            return self._forward_lstm(input_var, input_lengths)
         return encode_many([self], input_var, input_lengths)[0]
+
+    def _forward_lstm(self, input_var, input_lengths=None):
+        """nn.LSTM(batch_first, bidirectional) over packed sequences (encoder/rnn_encoder.py:49-55 with rnn_cell='lstm')
+        -> (output [B,L,dirs*H], (h_n, c_n) each [layers*dirs,B,H])"""
+        dev = input_var.device
+        lens = None
+        if self.variable_lengths and input_lengths is not None:
+            lens = torch.as_tensor(list(input_lengths), dtype=torch.int32).to(dev, non_blocking=True)
+            input_var = input_var[:, :int(max(input_lengths))].contiguous()
+        x = lookup(self.embedding, input_var, GLOBAL_SEEDS)
+        hn, cn = [], []
+        for layer in range(self.n_layers):
+            if layer > 0 and self.training and self.rnn_droprate > 0.0:
+                x = ops.dropout(x, self.rnn_droprate, GLOBAL_SEEDS.next())
+            params = [self.rnn.layer_params(layer, sfx) for sfx in self.rnn.suffixes()]
+            # b_ih's gradient comes out of the recurrence's backward (as for the GRU)
+            xps = ops.linear_many([(x, wih, bih.detach()) for wih, _, bih, _ in params])
+            outs = []
+            for di, ((wih, whh, bih, bhh), xp) in enumerate(zip(params, xps)):
+                o, h, c = ops.lstm_layer(xp, whh, bhh, bih=bih, lengths=lens, reverse=di == 1)
+                outs.append(o)
+                hn.append(h)
+                cn.append(c)
+            x = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+        return x, (torch.stack(hn, 0), torch.stack(cn, 0))
 
 
 def encode_many(encoders, input_var, input_lengths=None):

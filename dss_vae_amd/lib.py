@@ -92,6 +92,8 @@ _SIGNATURES = {
     "dssvae_gru_cell": ([_P, _P, _P, _I, _I, _P, _P], _I),
     "dssvae_gru_step_fwd": ([_P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _P], _I),
     "dssvae_gru_step_bwd": ([_P, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P], _I),
+    "dssvae_lstm_step_fwd": ([_P, _L, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P], _I),
+    "dssvae_lstm_step_bwd": ([_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P], _I),
     "dssvae_skinny_supported": ([_I, _I, _I, _L, _L, _L], _I),
     "dssvae_skinny_argmax_splits": ([_I, _I], _I),
     "dssvae_skinny_linear": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P], _I),

@@ -1141,6 +1141,104 @@ def gru_layer(insts, lengths=None, save=None, check=False):
     return list(res[:len(groups)]), list(res[len(groups):])
 
 
+# ----------------------------------------------------------------------------------------------
+# LSTM (rnn_cell = "lstm" of the reference's RNNBase): stepwise -- per timestep the recurrent product on the MFMA
+# GEMM + one fused cell kernel (dssvae_lstm_step_*), same saved-history idea as the stepwise GRU
+# ----------------------------------------------------------------------------------------------
+class _LstmFn(Function):
+    """(xproj [B,T,4H] incl. b_ih, whh [4H,H], bhh [4H], h0 [B,H], c0 [B,H], bih [4H] or empty -- gradient routing
+    only) -> (out [B,T,H], h_T, c_T); gate order i, f, g, o; lengths: packed-sequence semantics; reverse: walks
+    t = T-1 .. 0."""
+
+    @staticmethod
+    def forward(ctx, x, whh, bhh, h0, c0, bih, lengths, reverse):
+        L.require_cuda(x, whh)
+        ctx.set_materialize_grads(False)
+        B, T, G = x.shape
+        H = whh.size(1)
+        assert G == 4 * H and whh.size(0) == 4 * H
+        dev = x.device
+        lib = L.load()
+        save = torch.is_grad_enabled() or any(ctx.needs_input_grad[:6])
+        whh, bhh = whh.contiguous(), bhh.contiguous()
+        ldx = _xproj_ld(x)
+        out = torch.empty(B, T, H, device=dev, dtype=torch.float32)
+        gates = torch.empty(B, T, 7 * H, device=dev, dtype=torch.float32) if save else None
+        gh = torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
+        h, c = h0.contiguous(), c0.contiguous()
+        lp = None if lengths is None else lengths.data_ptr()
+        for step in range(T):
+            t = T - 1 - step if reverse else step
+            mm_nt(h, whh, out=gh)
+            hn, cn = torch.empty_like(h), torch.empty_like(c)
+            L.check(lib.dssvae_lstm_step_fwd(
+                x.data_ptr() + 4 * t * ldx, T * ldx, L.ptr(gh), L.ptr(bhh), L.ptr(h), L.ptr(c), lp, t, B, H, L.ptr(hn),
+                L.ptr(cn), out.data_ptr() + 4 * t * H, T * H,
+                None if gates is None else gates.data_ptr() + 4 * t * 7 * H, T * 7 * H, L.stream()),
+                "dssvae_lstm_step_fwd")
+            h, c = hn, cn
+        ctx.save_for_backward(whh, gates)
+        ctx.lengths, ctx.reverse, ctx.dims = lengths, bool(reverse), (B, T, H)
+        ctx.refs = (whh, bhh, bih)
+        return out, h, c
+
+    @staticmethod
+    def backward(ctx, dout, dhT, dcT):
+        whh, gates = ctx.saved_tensors
+        B, T, H = ctx.dims
+        if (dout is None and dhT is None and dcT is None) or gates is None:
+            return (None,) * 8
+        dev = whh.device
+        lib = L.load()
+        dout = None if dout is None else dout.contiguous()
+        dg = torch.empty(B, T, 4 * H, device=dev, dtype=torch.float32)
+        dh = None if dhT is None else dhT.contiguous()
+        dc = None if dcT is None else dcT.contiguous()
+        lp = None if ctx.lengths is None else ctx.lengths.data_ptr()
+        for step in range(T):
+            fstep = T - 1 - step
+            t = T - 1 - fstep if ctx.reverse else fstep
+            dhz = torch.empty(B, H, device=dev, dtype=torch.float32)
+            dcp = torch.empty(B, H, device=dev, dtype=torch.float32)
+            L.check(lib.dssvae_lstm_step_bwd(
+                gates.data_ptr() + 4 * t * 7 * H, T * 7 * H, None if dout is None else dout.data_ptr() + 4 * t * H,
+                0 if dout is None else T * H, L.ptr(dh), L.ptr(dc), lp, t, B, H, dg.data_ptr() + 4 * t * 4 * H, T * 4 * H,
+                L.ptr(dhz), L.ptr(dcp), L.stream()), "dssvae_lstm_step_bwd")
+            mm_nn(dg[:, t, :], whh, out=dhz, beta=1.0)
+            dh, dc = dhz, dcp
+        need = ctx.needs_input_grad
+        W_ref, bhh_ref, bih_ref = ctx.refs
+        rows = B * T
+        dg2 = dg.view(rows, 4 * H)
+        dW = mm_tn(dg2, gates.view(rows, 7 * H)[:, 5 * H:6 * H], out=_claim(W_ref, need[1])) if need[1] else None
+        db = colsum(dg2) if (need[2] or need[5]) else None
+        return (dg if need[0] else None, dW, db if need[2] else None, dh if need[3] else None, dc if need[4] else None,
+                db if (need[5] and bih_ref.numel()) else None, None, None)
+
+
+def lstm_layer(xproj, whh, bhh, h0=None, c0=None, bih=None, lengths=None, reverse=False):
+    """one LSTM recurrence over precomputed input projections -> (out [B,T,H], h_T, c_T)"""
+    B, H = xproj.size(0), whh.size(1)
+    z = None
+    if h0 is None or c0 is None:
+        z = torch.zeros(B, H, device=xproj.device, dtype=torch.float32)
+    empty = torch.empty(0, device=xproj.device)
+    return _LstmFn.apply(xproj, whh, bhh, z if h0 is None else h0, z if c0 is None else c0,
+                         empty if bih is None else bih, lengths, bool(reverse))
+
+
+def lstm_cell(gi, gh, c):
+    """one LSTM cell step from gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (greedy loop) -> (h', c')"""
+    L.require_cuda(gi, gh, c)
+    B, H = c.shape
+    hn, cn = torch.empty_like(c), torch.empty_like(c)
+    zero_b = torch.zeros(4 * H, device=c.device, dtype=torch.float32)
+    gi, gh, c = gi.contiguous(), gh.contiguous(), c.contiguous()
+    L.check(L.load().dssvae_lstm_step_fwd(L.ptr(gi), 4 * H, L.ptr(gh), L.ptr(zero_b), None, L.ptr(c), None, 0, B, H,
+                                          L.ptr(hn), L.ptr(cn), None, 0, None, 0, L.stream()), "dssvae_lstm_step_fwd")
+    return hn, cn
+
+
 def gru_cell(gi, gh, h):
     L.require_cuda(gi, gh, h)
     out = torch.empty_like(h)

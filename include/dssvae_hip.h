@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits */
+#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -275,6 +275,22 @@ int dssvae_gru_step_fwd(const float* x_t, int64_t x_row_stride, const float* gh,
 int dssvae_gru_step_bwd(const float* gates_t, int64_t gates_row_stride, const float* dout_t,
                         int64_t dout_row_stride, const float* dh, const int32_t* lengths, int t, int B, int H,
                         float* dgx_t, float* dgh_t, int64_t dg_row_stride, float* dhz, void* stream);
+
+/* LSTM cell (nn.LSTM behind RNNBase's rnn_cell = "lstm", networks/rnn_base.py:32-36; encoder/rnn_encoder.py:28,52;
+ * decoder/rnn_decoder.py:43,65), stepwise like dssvae_gru_step_*: the caller computes gh = h_{t-1} W_hh^T [B,4H] with
+ * dssvae_gemm_f32, these fuse the cell of ONE timestep (gate order i, f, g, o; pointers pre-offset to timestep t).
+ * fwd: h_new, c_new [B,H]; out_t (may be NULL); gates_t (may be NULL): the saved row [i|f|g|o|c_{t-1}|h_{t-1}|tanh c_t]
+ *      (row stride >= 7H).  Rows with t >= lengths[b] keep (h, c) and output 0 (packed-sequence semantics).
+ * bwd: dh, dc = gradients wrt (h_t, c_t) from t+1 (NULL = 0), dout_t (may be NULL) -> dg_t [B,4H] (gradient wrt the gate
+ *      pre-activations, the same for the input and the recurrent product), dhz [B,H] (the part of dh_{t-1} that does
+ *      not pass through W_hh: the caller forms dh_{t-1} = dhz + dg_t W_hh) and dc_prev [B,H]. */
+int dssvae_lstm_step_fwd(const float* x_t, int64_t x_row_stride, const float* gh, const float* bhh,
+                         const float* h_prev, const float* c_prev, const int32_t* lengths, int t, int B, int H,
+                         float* h_new, float* c_new, float* out_t, int64_t out_row_stride, float* gates_t,
+                         int64_t gates_row_stride, void* stream);
+int dssvae_lstm_step_bwd(const float* gates_t, int64_t gates_row_stride, const float* dout_t, int64_t dout_row_stride,
+                         const float* dh, const float* dc, const int32_t* lengths, int t, int B, int H, float* dg_t,
+                         int64_t dg_row_stride, float* dhz, float* dc_prev, void* stream);
 
 /* Skinny projections (M <= DSSVAE_SKINNY_MAX_ROWS activation rows: one decode batch), the per-step
  * products of the greedy loop (decoder/rnn_decoder.py:61-73 called from :160-168):

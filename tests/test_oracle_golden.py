@@ -171,3 +171,21 @@ def test_three_optimisation_steps(case):
         close(sd[k], v, rtol=1e-5, atol=1e-5, what="final " + k)
     for n, p in m.named_parameters():
         assert bool(p.requires_grad) == g["steps_requires_grad"][n], n
+
+
+def test_lstm_fixture_is_what_nn_lstm_computes():
+    """rnn_cell='lstm' (SURVEY 8f N4): the reference's RNNEncoder is embedding -> pack -> torch.nn.LSTM -> pad; the
+    CPU restatement of that (plain nn.LSTM here) reproduces the fixture the reference wrote, so the GPU test's
+    expectations are pinned from both sides."""
+    import torch.nn as nn
+    from conftest import load_golden
+    g = load_golden("lstm_encdec")
+    sd = g["enc_state"]
+    rnn = nn.LSTM(g["E"], g["H"], g["L"], batch_first=True, bidirectional=True)
+    rnn.load_state_dict({k[len("rnn."):]: v for k, v in sd.items() if k.startswith("rnn.")})
+    emb = sd["embedding.embeddings.weight"][g["enc_ids"]]
+    packed = nn.utils.rnn.pack_padded_sequence(emb, g["enc_lengths"], batch_first=True)
+    out, (hn, cn) = rnn(packed)
+    out, _ = nn.utils.rnn.pad_packed_sequence(out, batch_first=True)
+    assert torch.allclose(out, g["enc_out"], atol=1e-6) and torch.allclose(hn, g["enc_hn"], atol=1e-6)
+    assert torch.allclose(cn, g["enc_cn"], atol=1e-6)
