@@ -164,6 +164,54 @@ class RNNDecoder(RNNBase):
     def init_state(self, encoder_hidden):
         return encoder_hidden
 
+    def step(self, input_var, hidden, encoder_outputs=None, function=F.log_softmax):
+        """the single-step method TopKDecoder.forward calls on its decoder (beam_decoder.py:148): forward_step"""
+        return self.forward_step(input_var, hidden, encoder_outputs, function)
+
+    def valid_args(self, inputs, encoder_hidden, encoder_outputs, function, teacher_forcing_ratio):
+        """-> (inputs, batch_size, max_length), rnn_decoder.py:175-203"""
+        if inputs is None and encoder_hidden is None:
+            batch_size = 1
+        elif inputs is not None:
+            batch_size = inputs.size(0)
+        else:
+            batch_size = (encoder_hidden[0] if isinstance(encoder_hidden, tuple) else encoder_hidden).size(1)
+        if inputs is None:
+            if teacher_forcing_ratio > 0:
+                raise ValueError("Teacher forcing has to be disabled (set 0) when no inputs is provided.")
+            dev = ((encoder_hidden[0] if isinstance(encoder_hidden, tuple) else encoder_hidden).device
+                   if encoder_hidden is not None else self.out.weight.device)
+            inputs = torch.full((batch_size, 1), self.sos_id, dtype=torch.int64, device=dev)
+            max_length = self.max_length
+        else:
+            max_length = inputs.size(1) - 1
+        return inputs, batch_size, max_length
+
+    @torch.no_grad()
+    def step_rows(self, tok, h, c=None, out=None, function=F.log_softmax):
+        """One generation step on the cell kernels, for searches that keep many rows alive (beam search):
+        tok [N] int64; h (and c for the LSTM): per-layer lists of [N,H] -> (function(logits) [N,V], h', c').
+        F.log_softmax rows are written into `out` [N,V] when given (projection + log-sum-exp in one kernel)."""
+        emb = lookup(self.embedding, tok, GLOBAL_SEEDS)
+        x, hn, cn = emb, [], []
+        for l in range(self.n_layers):
+            if l > 0 and self.training and self.rnn_droprate > 0.0:
+                x = ops.dropout(x, self.rnn_droprate, GLOBAL_SEEDS.next())
+            wih, whh, bih, bhh = self.rnn.layer_params(l)
+            if self.is_lstm:
+                x, cl = ops.lstm_cell(ops.mm_nt(x, wih, bih), ops.mm_nt(h[l], whh, bhh), c[l])
+                cn.append(cl)
+            else:
+                x = ops.gru_cell(ops.mm_nt(x, wih, bih), ops.mm_nt(h[l], whh, bhh), h[l])
+            hn.append(x)
+        if function is F.log_softmax:
+            logp = ops.linear_log_softmax(x, emb, self.out.weight, self.out.bias, out=out)
+        else:
+            logp = function(ops.mm_nt(torch.cat((x, emb), dim=-1), self.out.weight, self.out.bias), dim=-1)
+            if out is not None:
+                logp = out.copy_(logp)
+        return logp, hn, (cn if self.is_lstm else None)
+
 
 def prepare_job(job):
     """embedding rows of a scoring job, looked up NOW (records autograd under the current

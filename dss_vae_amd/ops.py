@@ -790,6 +790,26 @@ def linear_argmax(xh, xe, W, b):
     return arg
 
 
+def linear_log_softmax(xh, xe, W, b, out=None):
+    """log_softmax of the projection, materialised [M, N] (beam search keeps every step's rows: beam_decoder.py:152-153):
+    the LSE kernel stores the logits beside its online log-sum-exp, one in-place pass then subtracts it.  `out`: a
+    caller buffer [M, N] (row stride free) the rows are written to.  Forward only."""
+    L.require_cuda(xh, W)
+    xh, ldh = _rows(_f32(xh))
+    if xe is not None:
+        xe, lde = _rows(_f32(xe))
+        Ke = xe.size(1)
+    else:
+        lde, Ke = 0, 0
+    W, ldw = _rows(W)
+    M, N = xh.size(0), W.size(0)
+    if out is None:
+        out = torch.empty(M, N, device=xh.device, dtype=torch.float32)
+    assert out.shape == (M, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    lse, _ = _lse(xh, ldh, xh.size(1), xe, lde, Ke, W, ldw, b, M, N, logits=out)
+    return out.sub_(lse.unsqueeze(1))
+
+
 # ----------------------------------------------------------------------------------------------
 # Persistent GRU
 # ----------------------------------------------------------------------------------------------
