@@ -1,18 +1,25 @@
 // Persistent GRU recurrence for gfx950 (forward and backward through time).
 //
 // Decomposition: an "instance" is one independent recurrence (a direction of an encoder, a decoder
-// layer, a task head).  Each instance is cut into (batch block of 64 rows) x (slice of 16 hidden
-// units); one 256-thread workgroup owns one cell of that grid for ALL timesteps:
+// layer, a task head).  Each instance is cut into cells of (batch block of 16 .. 128 rows) x (slice of 16 hidden
+// units); one workgroup owns one cell for ALL timesteps of the launch:
 //   * its W_hh slice (3 gates x 16 units x H, fp32) is loaded into LDS once and stays resident;
-//   * per step each of its 4 waves multiplies 16 batch rows of h_{t-1} (B operand) with the
-//     resident slice (A operand) on v_mfma_f32_16x16x4_f32, then applies the fused gate math in
-//     registers and stores its 16x16 piece of h_t;
-//   * the state is exchanged through a ping-pong buffer laid out [slice][row][16 units], so a
-//     workgroup publishes ONE contiguous 4 KB block and a reading wave takes 1 KB contiguous per
-//     slice; the waves that own the same 16 batch rows in the workgroups of one (instance, batch
-//     block) meet on one monotonic arrival counter per step -- there is no grid-wide barrier and no
-//     workgroup barrier in the step loop, and independent instances / batch blocks / row groups never
-//     wait for each other.
+//   * a cell is 1 .. 8 row groups of 16 batch rows; per step a row group multiplies its 16 rows of h_{t-1}
+//     (B operand) with the resident slice (A operand) on v_mfma_f32_16x16x4_f32, applies the fused gate math in
+//     registers and stores its 16x16 piece of h_t.  In the 16-wave layouts a row group is KS = 2 or 4 waves on
+//     different SIMDs that split the K range of the product and meet through LDS (see lds_signal below); in the
+//     4- / 8-wave layouts it is one wave;
+//   * the state is exchanged through a ping-pong buffer laid out [slice][row][16 units], so a row group
+//     publishes ONE contiguous 1 KB block per step and reads 1 KB contiguous per slice; the row groups that own
+//     the same 16 batch rows in the workgroups of one (instance, batch block) meet on one monotonic arrival
+//     counter per step -- there is no grid-wide barrier and no workgroup barrier in the step loop, and
+//     independent instances / batch blocks / row groups never wait for each other.
+// A launch may cover steps [t0, t0 + T) of a longer recurrence (inst.t0 / T_total): the caller cuts a launch in
+// time where its short recurrences end, so that the long ones continue in finer cells (ops._segments).
+// Measured where a step goes (tools/gru_phases.py, -DGRU_PROFILE build; 2 x B256 H300, 64-row cells, KS = 4):
+// 7.9 us = counter match 2.0 | exchange loads + own products 2.0 | partial sums of the other parts 1.4 |
+// gate math 0.05 | state store drained 1.2 | signal 0.6 | history stores 0.8 -- four dependent memory round
+// trips per step; the arithmetic is a quarter of it.
 // Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first table row): EVERY byte of
 // the exchange buffer is stored write-through (buffer_store_dwordx4 sc1) and EVERY load of it is a
 // buffer_load_dwordx4 sc1 (bypasses the CU's L1), so no release / acquire cache maintenance is
@@ -28,6 +35,7 @@
 //
 // Roofline: per step 2*B*H*3H flop on fp32 MFMA; in practice latency-bound by the step hand-off.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 namespace {
@@ -37,6 +45,9 @@ constexpr int CH = 8;    // exchange slices fetched per register chunk (forward)
 constexpr int CHB = 6;   // ... backward (measured: 8 -> 6 takes 6 % off the backward launches, forward loses 3 %)
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 constexpr int CNT_STRIDE = 32;  // one 128-B line per counter
+constexpr int PART_BYTES = 64 * 16;      // LDS per non-lead wave and partial sum (forward: 3 gates; backward: 1)
+constexpr int SYNC_WORDS = 64;           // LDS words behind them: [0,16) release per row group, [32,64) done per wave
+constexpr int LDS_MAX = 160 * 1024;
 constexpr int LDS_BUDGET = 150 * 1024;  // W_hh slice of a workgroup
 constexpr int MAX_WG_PER_CU = 4;
 
@@ -104,7 +115,61 @@ __device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+// K split INSIDE a workgroup: the KS waves of a row group (on KS different SIMDs) each take 1/KS of the exchange
+// slices -- a KS-th of the loads in flight per wave and of the dependent MFMA chain -- and meet through LDS: the
+// lead wave (part 0) polls the row group's counter and releases the others through an LDS word (the relayed form
+// of the hand-off table's first row: "the other waves load ... after an LDS word it then sets"); the others leave
+// their partial sums in LDS and raise a word each; the lead adds them up, applies the gate math and publishes.
+typedef __attribute__((address_space(3))) volatile unsigned lds_word;  // LDS address space: ds_ instructions, not flat
+__device__ __forceinline__ void lds_signal(lds_word* w, unsigned v) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // what this wave wrote to LDS before is there
+    *w = v;
+}
+__device__ __forceinline__ void lds_await(lds_word* w, unsigned target, unsigned* err) {
+    unsigned spins = 0;
+    while (*w < target) {
+        __builtin_amdgcn_s_sleep(0);
+        if ((++spins & 4095u) == 0 &&
+            (spins > SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+// The gate math sits on the step's critical path in ONE wave (4 values per lane, 12 transcendentals): hardware
+// exp2 / rcp (1 ulp each) instead of the library's division and tanhf -- ~0.6 us of VALU time per step less.
+// |error| <= ~2e-7 absolute, inside the fp32 noise of the 300..600-term dot products that feed the gates.
+__device__ __forceinline__ float sigm(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanh_fast(float x) {
+    return 1.f - 2.f * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
+
+// Development build only (-DGRU_PROFILE, tools/gru_phases.py): 100 MHz timestamps of the step's phases, taken by the
+// lead wave of row group 0 in a few sampled workgroups.  Not compiled into the shipped library.
+#ifdef GRU_PROFILE
+constexpr int PROF_WG = 4, PROF_STEPS = 128, PROF_PH = 8;
+__device__ unsigned long long g_prof[PROF_WG][PROF_STEPS][PROF_PH];
+__device__ unsigned long long g_prof_part[PROF_WG][PROF_STEPS][4];  // wave 1 (a non-lead part): top, released, products, signalled
+__device__ unsigned g_simd[PROF_WG][16];  // SIMD id (HW_REG_HW_ID[5:4]) of every wave of the sampled workgroups
+#define PROF_SLOT(nwg) ((int)blockIdx.x == 0 ? 0 : (int)blockIdx.x == (nwg) / 3 ? 1 : (int)blockIdx.x == 2 * (nwg) / 3 ? 2 \
+                        : (int)blockIdx.x == (nwg) - 1 ? 3 : -1)
+#define PROFP(ph)                                                                                              \
+    do {                                                                                                       \
+        if (wave >= 1 && wave <= 3 && blockIdx.x == 0 && step < PROF_STEPS && lane == 0)                      \
+            g_prof_part[wave][step][ph] = wall_clock64();                                                     \
+    } while (0)
+#define PROF(ph)                                                                                     \
+    do {                                                                                             \
+        if (prof_slot >= 0 && step < PROF_STEPS && lane == 0) g_prof[prof_slot][step][ph] = wall_clock64(); \
+    } while (0)
+#else
+#define PROF(ph) do {} while (0)
+#define PROFP(ph) do {} while (0)
+#endif
 
 __device__ __forceinline__ void load4(float (&v)[4], const float* p, bool vec, int n_ok) {
     if (vec && n_ok >= 4) {
@@ -142,6 +207,7 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, in
 template <int WV>
 __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     constexpr int NTHR = 64 * WV;
+    constexpr int CHF = WV > 8 ? 5 : CH;
     // Ws[g][slice s][c][kq][j] = whh[(g*H + u0 + j)*H + 16 s + 4 kq + c]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -151,19 +217,27 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
     const int H = in.H, T = in.T, B = in.B, NS = d.n_slices;
-    // cells of this instance hold BB batch rows (<= 16 WV): waves beyond BB / 16 only help to fill LDS
-    const int BB = d.rows, WVI = BB >> 4, BLK = BB * UU;
+    // cells of this instance hold BB batch rows = WVI row groups of 16; the WV waves are KS per row group
+    const int BB = d.rows, WVI = BB >> 4, KS = WV / WVI, BLK = BB * UU;
     const int Tt = in.T_total > 0 ? in.T_total : T;   // row stride of the [B, T_total, .] histories
     const int u0 = slice * UU;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // row group and part of the K range; the lead (part 0) of row group r is its wave r % KS, so that the leads of a
+    // workgroup -- the waves that also poll, reduce, apply the gates and publish -- sit on different SIMDs
+    const int rg = wave / KS, kp = (wave - rg * KS + KS - rg % KS) % KS;
+    const bool lead = kp == 0;
     const int j = lane & 15, kq = lane >> 4;
-    const int b = bblock * BB + wave * 16 + j;
+    const int b = bblock * BB + rg * 16 + j;
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;                       // first of this lane's 4 units
     const int n_ok = max(0, min(4, H - ub));          // how many of them exist
-    unsigned* cnt = d.counters + ((size_t)bblock * WVI + wave) * CNT_STRIDE;  // this wave's row group
+    unsigned* cnt = d.counters + ((size_t)bblock * WVI + rg) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
     const int gate_stride = NS * 256;
+    // behind the slice, only there (and touched) when KS > 1: a slot of partial sums per non-lead wave, sync words
+    f32x4* parts = reinterpret_cast<f32x4*>(Ws + 3 * NS * 256);
+    lds_word* sync = (lds_word*)(parts + (WV - WVI) * 3 * 64);
+    const int slot0 = rg * (KS - 1);  // first slot of this row group's non-lead waves
 
     for (int idx = threadIdx.x; idx < 3 * NS * 256; idx += NTHR) {
         const int g = idx / (NS * 256), rem = idx % (NS * 256);
@@ -173,6 +247,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         const int s = k >> 4, kk = k & 15;
         Ws[g * gate_stride + s * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + jj] = w;
     }
+    if (KS > 1 && threadIdx.x < SYNC_WORDS) sync[threadIdx.x] = 0u;
     float bh[3][4];
 #pragma unroll
     for (int g = 0; g < 3; ++g)
@@ -180,55 +255,99 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         for (int c = 0; c < 4; ++c) bh[g][c] = (c < n_ok) ? in.bhh[g * H + ub + c] : 0.f;
     const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
 
-    // exchange buffers of this batch block: [2][NS][64][16]; this lane's piece of its own block
+    // exchange buffers of this batch block: [2][NS][BB][16]; this lane's piece of its own block
     const unsigned half_bytes = (unsigned)NS * BLK * 4u;
     float* hx0 = d.hx + (size_t)bblock * NS * BLK;
     float* hx1 = hx0 + (size_t)d.n_bblocks * NS * BLK;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(hx0, half_bytes), rs1 = make_rsrc(hx1, half_bytes);
-    const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;  // same lane offset inside every slice block
+    const __amdgpu_buffer_rsrc_t ws0 = make_rsrc(hx0, half_bytes), ws1 = make_rsrc(hx1, half_bytes);
+    // this wave's part of the slices: a resource of its own, so that loads past the part fetch nothing
+    const int per = (NS + KS - 1) / KS, s_lo = min(NS, kp * per), s_n = min(NS - s_lo, per);
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(hx0 + (size_t)s_lo * BLK, (unsigned)s_n * BLK * 4u),
+                                 rs1 = make_rsrc(hx1 + (size_t)s_lo * BLK, (unsigned)s_n * BLK * 4u);
+    const int voff = ((rg * 16 + j) * UU + 4 * kq) * 4;  // same lane offset inside every slice block
     const int own = slice * BLK * 4;
+    lds_word* go = sync + rg;
+    lds_word* done = sync + 32 + wave;
 
     __syncthreads();  // the slice is in LDS for every wave; from here on the waves run free
-    if (wave >= WVI) return;
     // state 0 into the exchange buffer (pad units and pad rows are zero and stay zero)
     float hcur[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
-    st_sc1((f32x4){hcur[0], hcur[1], hcur[2], hcur[3]}, rs0, voff, own);
-    publish(cnt);
+    if (lead) {
+        if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
+        st_sc1((f32x4){hcur[0], hcur[1], hcur[2], hcur[3]}, ws0, voff, own);
+        publish(cnt);
+    }
 
-    const float* Wl = Ws + kq * 16 + j;
+    const float* Wl = Ws + s_lo * 256 + kq * 16 + j;
+#ifdef GRU_PROFILE
+    const int prof_slot = (wave == 0) ? PROF_SLOT((int)gridDim.x) : -1;
+    if (PROF_SLOT((int)gridDim.x) >= 0 && lane == 0 && wave < 16)
+        g_simd[PROF_SLOT((int)gridDim.x)][wave] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+#endif
     for (int step = 0; step < T; ++step) {
+        PROF(0);
         const int gs = in.t0 + step;  // step of the whole recurrence (this launch runs steps t0 .. t0 + T - 1)
         const int t = in.reverse ? Tt - 1 - gs : gs;
-        const __amdgpu_buffer_rsrc_t rin = (step & 1) ? rs1 : rs0, rout = (step & 1) ? rs0 : rs1;
+        const __amdgpu_buffer_rsrc_t rin = (step & 1) ? rs1 : rs0, rout = (step & 1) ? ws0 : ws1;
         // the x-projection gates of this step do not depend on the hand-off: fetch them first
         const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
-        const float* xp = in.xproj + bt * in.ldx;
         float xr[4], xz[4], xn[4];
-        const bool vec_x = vec_h && (in.ldx % 4) == 0;
-        load4(xr, xp + ub, vec_x, n_ok);
-        load4(xz, xp + H + ub, vec_x, n_ok);
-        load4(xn, xp + 2 * H + ub, vec_x, n_ok);
-
-        await(cnt, (unsigned)(step + 1) * NS, args.err);
+        if (lead) {
+            const float* xp = in.xproj + bt * in.ldx;
+            const bool vec_x = vec_h && (in.ldx % 4) == 0;
+            load4(xr, xp + ub, vec_x, n_ok);
+            load4(xz, xp + H + ub, vec_x, n_ok);
+            load4(xn, xp + 2 * H + ub, vec_x, n_ok);
+            await(cnt, (unsigned)(step + 1) * NS, args.err);
+            PROF(1);
+            if (KS > 1) lds_signal(go, (unsigned)step + 1u);
+        } else {
+            PROFP(0);
+            lds_await(go, (unsigned)step + 1u, args.err);
+            PROFP(1);
+        }
 
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 cur[CH], nxt[CH];
+        f32x4 cur[CHF], nxt[CHF];
 #pragma unroll
-        for (int i = 0; i < CH; ++i) cur[i] = ld_sc1(rin, voff + i * BLK * 4, 0);  // past NS: out of range, no fetch
-        for (int s0 = 0; s0 < NS; s0 += CH) {
-            if (s0 + CH < NS) {
+        for (int i = 0; i < CHF; ++i) cur[i] = ld_sc1(rin, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
+        for (int s0 = 0; s0 < s_n; s0 += CHF) {
+            if (s0 + CHF < s_n) {
 #pragma unroll
-                for (int i = 0; i < CH; ++i) nxt[i] = ld_sc1(rin, voff + (s0 + CH + i) * BLK * 4, 0);
+                for (int i = 0; i < CHF; ++i) nxt[i] = ld_sc1(rin, voff + (s0 + CHF + i) * BLK * 4, 0);
             }
 #pragma unroll
-            for (int i = 0; i < CH; ++i)
-                if (s0 + i < NS) mfma_chunk<3>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
+            for (int i = 0; i < CHF; ++i)
+                if (s0 + i < s_n) mfma_chunk<3>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) cur[i] = nxt[i];
+            for (int i = 0; i < CHF; ++i) cur[i] = nxt[i];
         }
+        if (!lead) {
+#ifdef GRU_PROFILE
+            asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
+#endif
+            PROFP(2);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) parts[((slot0 + kp - 1) * 3 + g) * 64 + lane] = acc[g];
+            lds_signal(done, (unsigned)step + 1u);
+            PROFP(3);
+            continue;
+        }
+#ifdef GRU_PROFILE
+        asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));  // the products are there
+#endif
+        PROF(2);
+        for (int p = 1; p < KS; ++p) {
+            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, args.err);
+#ifdef GRU_PROFILE
+            if (p == 1) PROF(7);
+#endif
+#pragma unroll
+            for (int g = 0; g < 3; ++g) acc[g] += parts[((slot0 + p - 1) * 3 + g) * 64 + lane];
+        }
+        PROF(3);
         // fused gate math: lane holds units ub..ub+3 of batch row b (pad units keep writing zeros)
         const bool live = row_ok && t < len;
         float r[4], z[4], n[4], hn[4], hnew[4], outv[4];
@@ -237,16 +356,22 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             r[c] = sigm(xr[c] + acc[0][c] + bh[0][c]);
             z[c] = sigm(xz[c] + acc[1][c] + bh[1][c]);
             hn[c] = acc[2][c] + bh[2][c];
-            n[c] = tanhf(xn[c] + r[c] * hn[c]);
+            n[c] = tanh_fast(xn[c] + r[c] * hn[c]);
             const float hv = (1.f - z[c]) * n[c] + z[c] * hcur[c];
             hnew[c] = (c < n_ok && row_ok) ? (live ? hv : hcur[c]) : 0.f;
             outv[c] = live ? hv : 0.f;
         }
         // hand the new state over first; the history stores below then overlap the peers' next step
+        PROF(4);
         if (step + 1 < T) {
             st_sc1((f32x4){hnew[0], hnew[1], hnew[2], hnew[3]}, rout, voff, own);
+#ifdef GRU_PROFILE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            PROF(5);
+#endif
             publish(cnt);
         }
+        PROF(6);
         if (row_ok) {
             store4(in.out + bt * in.ldo + ub, outv, vec_h && (in.ldo % 4) == 0, n_ok);
             if (in.gates) {
@@ -261,7 +386,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) hcur[c] = hnew[c];
     }
-    if (row_ok && n_ok > 0 && in.h_last) store4(in.h_last + (size_t)b * H + ub, hcur, vec_h, n_ok);
+    if (lead && row_ok && n_ok > 0 && in.h_last) store4(in.h_last + (size_t)b * H + ub, hcur, vec_h, n_ok);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -270,6 +395,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 template <int WV>
 __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     constexpr int NTHR = 64 * WV;
+    constexpr int CB = WV > 8 ? 5 : CHB;
     // chunk q = 3*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -279,17 +405,23 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
     const int H = in.H, T = in.T, B = in.B, K = 3 * H, NS = d.n_slices, NQ = 3 * NS;
-    const int BB = d.rows, WVI = BB >> 4, BLK = BB * UU;
+    const int BB = d.rows, WVI = BB >> 4, KS = WV / WVI, BLK = BB * UU;
     const int Tt = in.T_total > 0 ? in.T_total : T;
     const int u0 = slice * UU;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rg = wave / KS, kp = (wave - rg * KS + KS - rg % KS) % KS;  // row group, part of the K range (see gru_fwd_kernel)
+    const bool lead = kp == 0;
     const int j = lane & 15, kq = lane >> 4;
-    const int b = bblock * BB + wave * 16 + j;
+    const int b = bblock * BB + rg * 16 + j;
     const bool row_ok = b < B;
     const int ub = u0 + 4 * kq;
     const int n_ok = max(0, min(4, H - ub));
-    unsigned* cnt = d.counters + ((size_t)bblock * WVI + wave) * CNT_STRIDE;  // this wave's row group
+    unsigned* cnt = d.counters + ((size_t)bblock * WVI + rg) * CNT_STRIDE;  // this wave's row group
     const bool vec_h = (H % 4) == 0;
+    // behind the slice, only there (and touched) when KS > 1: a partial sum per non-lead wave, sync words
+    f32x4* parts = reinterpret_cast<f32x4*>(Ws + NQ * 256);
+    lds_word* sync = (lds_word*)(parts + (WV - WVI) * 64);
+    const int slot0 = rg * (KS - 1);
 
     for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
         const int q = idx >> 8, rem = idx & 255;
@@ -299,20 +431,26 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         const float w = (cu < H && u < H) ? in.whh[(size_t)(g * H + cu) * H + u] : 0.f;
         Ws[q * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + i] = w;
     }
+    if (KS > 1 && threadIdx.x < SYNC_WORDS) sync[threadIdx.x] = 0u;
     const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
     float dh[4] = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok && in.dh_last) load4(dh, in.dh_last + (size_t)b * H + ub, vec_h, n_ok);
+    if (lead && row_ok && in.dh_last) load4(dh, in.dh_last + (size_t)b * H + ub, vec_h, n_ok);
 
     const unsigned half_bytes = (unsigned)NQ * BLK * 4u;
     float* gx0 = d.gx + (size_t)bblock * NQ * BLK;
     float* gx1 = gx0 + (size_t)d.n_bblocks * NQ * BLK;
-    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(gx0, half_bytes), rs1 = make_rsrc(gx1, half_bytes);
-    const int voff = ((wave * 16 + j) * UU + 4 * kq) * 4;
+    const __amdgpu_buffer_rsrc_t ws0 = make_rsrc(gx0, half_bytes), ws1 = make_rsrc(gx1, half_bytes);
+    // this wave's part of the gate blocks: a resource of its own, so that loads past the part fetch nothing
+    const int per = (NQ + KS - 1) / KS, q_lo = min(NQ, kp * per), q_n = min(NQ - q_lo, per);
+    const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(gx0 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u),
+                                 rs1 = make_rsrc(gx1 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u);
+    const int voff = ((rg * 16 + j) * UU + 4 * kq) * 4;
     const int own = slice * 3 * BLK * 4;
+    lds_word* go = sync + rg;
+    lds_word* done = sync + 32 + wave;
     __syncthreads();
-    if (wave >= WVI) return;
 
-    const float* Wl = Ws + kq * 16 + j;
+    const float* Wl = Ws + q_lo * 256 + kq * 16 + j;
     // bias gradients (column sums of dgx / dgh over batch and time) ride along in registers
     float sb_r[4] = {0.f, 0.f, 0.f, 0.f}, sb_z[4] = {0.f, 0.f, 0.f, 0.f}, sb_n[4] = {0.f, 0.f, 0.f, 0.f},
           sb_m[4] = {0.f, 0.f, 0.f, 0.f};
@@ -322,67 +460,73 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         const int t = in.reverse ? Tt - 1 - fstep : fstep;
         const __amdgpu_buffer_rsrc_t rcur = (step & 1) ? rs1 : rs0;
         float dhz[4] = {0.f, 0.f, 0.f, 0.f};
-        float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dgz[4] = {0.f, 0.f, 0.f, 0.f}, dgn[4] = {0.f, 0.f, 0.f, 0.f},
-              dgm[4] = {0.f, 0.f, 0.f, 0.f};
-        const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
-        if (row_ok && n_ok > 0) {
-            const bool live = t < len;
-            if (live) {
-                float go[4] = {0.f, 0.f, 0.f, 0.f};
-                if (in.dout) load4(go, in.dout + bt * in.ldd + ub, vec_h && (in.ldd % 4) == 0, n_ok);
-                const float* gs = in.gates + bt * 5 * H + ub;
-                float r[4], z[4], n[4], hn[4], hp[4];
-                load4(r, gs, vec_h, n_ok);
-                load4(z, gs + H, vec_h, n_ok);
-                load4(n, gs + 2 * H, vec_h, n_ok);
-                load4(hn, gs + 3 * H, vec_h, n_ok);
-                load4(hp, gs + 4 * H, vec_h, n_ok);
+        if (lead) {
+            const __amdgpu_buffer_rsrc_t wcur = (step & 1) ? ws1 : ws0;
+            float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dgz[4] = {0.f, 0.f, 0.f, 0.f}, dgn[4] = {0.f, 0.f, 0.f, 0.f},
+                  dgm[4] = {0.f, 0.f, 0.f, 0.f};
+            const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
+            if (row_ok && n_ok > 0) {
+                const bool live = t < len;
+                if (live) {
+                    float go_[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (in.dout) load4(go_, in.dout + bt * in.ldd + ub, vec_h && (in.ldd % 4) == 0, n_ok);
+                    const float* gs = in.gates + bt * 5 * H + ub;
+                    float r[4], z[4], n[4], hn[4], hp[4];
+                    load4(r, gs, vec_h, n_ok);
+                    load4(z, gs + H, vec_h, n_ok);
+                    load4(n, gs + 2 * H, vec_h, n_ok);
+                    load4(hn, gs + 3 * H, vec_h, n_ok);
+                    load4(hp, gs + 4 * H, vec_h, n_ok);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float g = dh[c] + go[c];
-                    const float dn = g * (1.f - z[c]) * (1.f - n[c] * n[c]);
-                    const bool ok = c < n_ok;
-                    dgn[c] = ok ? dn : 0.f;
-                    dgz[c] = ok ? g * (hp[c] - n[c]) * z[c] * (1.f - z[c]) : 0.f;
-                    dgr[c] = ok ? dn * hn[c] * r[c] * (1.f - r[c]) : 0.f;
-                    dgm[c] = ok ? dn * r[c] : 0.f;
-                    dhz[c] = g * z[c];
+                    for (int c = 0; c < 4; ++c) {
+                        const float g = dh[c] + go_[c];
+                        const float dn = g * (1.f - z[c]) * (1.f - n[c] * n[c]);
+                        const bool ok = c < n_ok;
+                        dgn[c] = ok ? dn : 0.f;
+                        dgz[c] = ok ? g * (hp[c] - n[c]) * z[c] * (1.f - z[c]) : 0.f;
+                        dgr[c] = ok ? dn * hn[c] * r[c] * (1.f - r[c]) : 0.f;
+                        dgm[c] = ok ? dn * r[c] : 0.f;
+                        dhz[c] = g * z[c];
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dhz[c] = dh[c];
                 }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) dhz[c] = dh[c];
             }
-        }
-        // this slice's three gate blocks (pad units / pad rows publish zeros); hand over first, the
-        // dgx / dgh history stores then overlap the wait
+            // this slice's three gate blocks (pad units / pad rows publish zeros); hand over first, the
+            // dgx / dgh history stores then overlap the wait
 #pragma unroll
-        for (int c = 0; c < 4; ++c) { sb_r[c] += dgr[c]; sb_z[c] += dgz[c]; sb_n[c] += dgn[c]; sb_m[c] += dgm[c]; }
-        st_sc1((f32x4){dgr[0], dgr[1], dgr[2], dgr[3]}, rcur, voff, own);
-        st_sc1((f32x4){dgz[0], dgz[1], dgz[2], dgz[3]}, rcur, voff, own + BLK * 4);
-        st_sc1((f32x4){dgm[0], dgm[1], dgm[2], dgm[3]}, rcur, voff, own + 2 * BLK * 4);
-        publish(cnt);
-        if (row_ok && n_ok > 0) {
-            float* ox = in.dgx + bt * K + ub;
-            float* oh = in.dgh + bt * K + ub;
-            store4(ox, dgr, vec_h, n_ok); store4(ox + H, dgz, vec_h, n_ok); store4(ox + 2 * H, dgn, vec_h, n_ok);
-            store4(oh, dgr, vec_h, n_ok); store4(oh + H, dgz, vec_h, n_ok); store4(oh + 2 * H, dgm, vec_h, n_ok);
+            for (int c = 0; c < 4; ++c) { sb_r[c] += dgr[c]; sb_z[c] += dgz[c]; sb_n[c] += dgn[c]; sb_m[c] += dgm[c]; }
+            st_sc1((f32x4){dgr[0], dgr[1], dgr[2], dgr[3]}, wcur, voff, own);
+            st_sc1((f32x4){dgz[0], dgz[1], dgz[2], dgz[3]}, wcur, voff, own + BLK * 4);
+            st_sc1((f32x4){dgm[0], dgm[1], dgm[2], dgm[3]}, wcur, voff, own + 2 * BLK * 4);
+            publish(cnt);
+            if (row_ok && n_ok > 0) {
+                float* ox = in.dgx + bt * K + ub;
+                float* oh = in.dgh + bt * K + ub;
+                store4(ox, dgr, vec_h, n_ok); store4(ox + H, dgz, vec_h, n_ok); store4(ox + 2 * H, dgn, vec_h, n_ok);
+                store4(oh, dgr, vec_h, n_ok); store4(oh + H, dgz, vec_h, n_ok); store4(oh + 2 * H, dgm, vec_h, n_ok);
+            }
+            await(cnt, (unsigned)(step + 1) * NS, args.err);
+            if (KS > 1) lds_signal(go, (unsigned)step + 1u);
+        } else {
+            lds_await(go, (unsigned)step + 1u, args.err);
         }
-        await(cnt, (unsigned)(step + 1) * NS, args.err);
 
         f32x4 acc[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        f32x4 cur[CHB], nxt[CHB];
+        f32x4 cur[CB], nxt[CB];
 #pragma unroll
-        for (int i = 0; i < CHB; ++i) cur[i] = ld_sc1(rcur, voff + i * BLK * 4, 0);  // past NQ: out of range, no fetch
-        for (int q0 = 0; q0 < NQ; q0 += CHB) {
-            if (q0 + CHB < NQ) {
+        for (int i = 0; i < CB; ++i) cur[i] = ld_sc1(rcur, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
+        for (int q0 = 0; q0 < q_n; q0 += CB) {
+            if (q0 + CB < q_n) {
 #pragma unroll
-                for (int i = 0; i < CHB; ++i) nxt[i] = ld_sc1(rcur, voff + (q0 + CHB + i) * BLK * 4, 0);
+                for (int i = 0; i < CB; ++i) nxt[i] = ld_sc1(rcur, voff + (q0 + CB + i) * BLK * 4, 0);
             }
 #pragma unroll
-            for (int i = 0; i < CHB; ++i)
-                if (q0 + i < NQ) {
+            for (int i = 0; i < CB; ++i)
+                if (q0 + i < q_n) {
                     // three independent accumulators in rotation hide the 40-cycle dependent latency
                     const float* w = Wl + (q0 + i) * 256;
                     f32x4& a = acc[i % 3];
@@ -390,11 +534,22 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                     for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * 64], cur[i][c], a, 0, 0, 0);
                 }
 #pragma unroll
-            for (int i = 0; i < CHB; ++i) cur[i] = nxt[i];
+            for (int i = 0; i < CB; ++i) cur[i] = nxt[i];
+        }
+        f32x4 sum = acc[0] + acc[1] + acc[2];
+        if (!lead) {
+            parts[(slot0 + kp - 1) * 64 + lane] = sum;
+            lds_signal(done, (unsigned)step + 1u);
+            continue;
+        }
+        for (int p = 1; p < KS; ++p) {
+            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, args.err);
+            sum += parts[(slot0 + p - 1) * 64 + lane];
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + acc[0][c] + acc[1][c] + acc[2][c];
+        for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + sum[c];
     }
+    if (!lead) return;
     if (row_ok && n_ok > 0 && in.dh0) store4(in.dh0 + (size_t)b * H + ub, dh, vec_h, n_ok);
     if (in.dbias_x || in.dbias_h) {
         // sum over the 16 batch rows of the wave (lanes with the same unit quad), then one atomic per unit
@@ -466,7 +621,8 @@ const void* fwd_kernel(int wv) {
         case 1: return reinterpret_cast<const void*>(gru_fwd_kernel<1>);
         case 2: return reinterpret_cast<const void*>(gru_fwd_kernel<2>);
         case 4: return reinterpret_cast<const void*>(gru_fwd_kernel<4>);
-        default: return reinterpret_cast<const void*>(gru_fwd_kernel<8>);
+        case 8: return reinterpret_cast<const void*>(gru_fwd_kernel<8>);
+        default: return reinterpret_cast<const void*>(gru_fwd_kernel<16>);
     }
 }
 const void* bwd_kernel(int wv) {
@@ -474,27 +630,34 @@ const void* bwd_kernel(int wv) {
         case 1: return reinterpret_cast<const void*>(gru_bwd_kernel<1>);
         case 2: return reinterpret_cast<const void*>(gru_bwd_kernel<2>);
         case 4: return reinterpret_cast<const void*>(gru_bwd_kernel<4>);
-        default: return reinterpret_cast<const void*>(gru_bwd_kernel<8>);
+        case 8: return reinterpret_cast<const void*>(gru_bwd_kernel<8>);
+        default: return reinterpret_cast<const void*>(gru_bwd_kernel<16>);
     }
 }
 
-inline int lds_bytes_for(int H_max) { return 3 * (round16(H_max) / UU) * 256 * (int)sizeof(float); }
+inline int slice_bytes_for(int H_max) { return 3 * (round16(H_max) / UU) * 256 * (int)sizeof(float); }
+// LDS of a launch: the resident W_hh slice; with the K split (some instance has more waves than row groups) the
+// waves' partial sums and the sync words behind it
+inline int lds_bytes_for(bool backward, int H_max, int wv, int min_rows) {
+    const int parts = wv - min_rows / 16;  // non-lead waves of the instance with the fewest row groups
+    return slice_bytes_for(H_max) + (parts > 0 ? parts * (backward ? 1 : 3) * PART_BYTES + SYNC_WORDS * 4 : 0);
+}
 
 // How many workgroups of a persistent launch the chip holds AT ONCE: the runtime's occupancy answer for this
-// kernel, block size and LDS slice, times the CU count.  Every workgroup of a launch must be resident (the step
+// kernel, block size and LDS size, times the CU count.  Every workgroup of a launch must be resident (the step
 // hand-off spins on peers), so this is the bound on the grid -- not the CU count: an H = 300 slice is 57 KB of
-// the CU's 160 KB of LDS, two such workgroups share a CU.  0 = the slice does not fit at all.
+// the CU's 160 KB of LDS, two such 4-wave workgroups share a CU.  0 = it does not fit at all.
 int resident_workgroups(bool backward, int wv, int lds_bytes) {
-    if (lds_bytes > LDS_BUDGET || lds_bytes <= 0) return 0;
-    // the answer depends on (kernel, block size, LDS slice) only: asked once (lds is a multiple of 3 KB)
-    static int cache[2][4][LDS_BUDGET / 3072 + 1];  // 0 = not asked yet, -1 = asked: none
-    const int wi = wv == 1 ? 0 : wv == 2 ? 1 : wv == 4 ? 2 : 3;
-    int& c = cache[backward ? 1 : 0][wi][lds_bytes / 3072];
+    if (lds_bytes > LDS_MAX || lds_bytes <= 0) return 0;
+    // the answer depends on (kernel, block size, LDS size) only: asked once (sizes are multiples of 256 B)
+    static int cache[2][5][LDS_MAX / 256 + 1];  // 0 = not asked yet, -1 = asked: none
+    const int wi = wv == 1 ? 0 : wv == 2 ? 1 : wv == 4 ? 2 : wv == 8 ? 3 : 4;
+    int& c = cache[backward ? 1 : 0][wi][lds_bytes / 256];
     if (c == 0) {
         const void* k = backward ? bwd_kernel(wv) : fwd_kernel(wv);
         int per_cu = 0;
-        // the attribute is per kernel, not per launch: raise it to the budget once, whatever this launch needs
-        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BUDGET) != hipSuccess ||
+        // the attribute is per kernel, not per launch: raise it to the CU's LDS once, whatever this launch needs
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess ||
             hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * wv, (size_t)lds_bytes) != hipSuccess)
             per_cu = 0;
         if (per_cu > MAX_WG_PER_CU) per_cu = MAX_WG_PER_CU;
@@ -503,11 +666,15 @@ int resident_workgroups(bool backward, int wv, int lds_bytes) {
     return c > 0 ? c : 0;
 }
 
-// cell height (batch rows per workgroup) of every instance and the launch's waves per workgroup.  An instance
-// may ask for its own height (inst.rows in {16, 32, 64, 128}); 0 = the library's choice for the whole launch:
-// 64 rows when the grid is resident that way, else 128.  DSSVAE_GRU_WAVES=8 forces 128 (tests).
-// -> waves per workgroup (1, 2, 4, 8), 0 = not resident either way, -1 = bad rows value
-int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want, int* rows_out) {
+// Cell height (batch rows per workgroup) of every instance, the launch's waves per workgroup and its LDS size.  An
+// instance may ask for its own height (inst.rows in {16, 32, 64, 128}); 0 = the library's choice for the whole
+// launch.  Tried in this order, the first whose grid is resident wins:
+//   64-row cells in 16-wave workgroups (4 row groups x K split 4), 128-row cells in 16-wave workgroups (8 x 2),
+//   then the layouts without K split: 64 rows / 4 waves (several workgroups per CU), 128 rows / 8 waves.
+// DSSVAE_GRU_WAVES=8 forces 128 rows / 8 waves, DSSVAE_GRU_KSPLIT=0 skips the K-split layouts (tests, A/B).
+// -> waves per workgroup (1 .. 16), 0 = not resident any way, -1 = bad rows value
+int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want, int* rows_out,
+              int* lds_out) {
     int max_h = 0;
     bool any_auto = false;
     for (int i = 0; i < n_inst; ++i) {
@@ -515,19 +682,33 @@ int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, con
         if (want[i] == 0) any_auto = true;
         else if (want[i] != 16 && want[i] != 32 && want[i] != 64 && want[i] != 128) return -1;
     }
-    const int lds = lds_bytes_for(max_h);
     const char* f = getenv("DSSVAE_GRU_WAVES");
     const bool force8 = f && atoi(f) == 8;
-    const int cand[2] = {force8 ? 128 : 64, 128};
-    for (int c = 0; c < (any_auto ? 2 : 1); ++c) {
-        int wg = 0, max_rows = 16;
+    const char* ks = getenv("DSSVAE_GRU_KSPLIT");
+    const bool ksplit_ok = !force8 && !(ks && atoi(ks) == 0);
+    struct Cand { int rows, wv16; };
+    const Cand cand[4] = {{64, 1}, {128, 1}, {force8 ? 128 : 64, 0}, {128, 0}};
+    for (int c = ksplit_ok ? 0 : 2; c < 4; ++c) {
+        if (!any_auto && (c == 1 || c == 3)) continue;  // every height is given: the row candidates do not differ
+        int wg = 0, max_rows = 16, min_rows = 128;
         for (int i = 0; i < n_inst; ++i) {
-            rows_out[i] = want[i] ? want[i] : cand[c];
+            rows_out[i] = want[i] ? want[i] : cand[c].rows;
             wg += ((B[i] + rows_out[i] - 1) / rows_out[i]) * (round16(H[i]) / UU);
             if (rows_out[i] > max_rows) max_rows = rows_out[i];
+            if (rows_out[i] < min_rows) min_rows = rows_out[i];
         }
-        const int wv = max_rows / 16;
-        if (wg <= resident_workgroups(backward, wv, lds)) return wv;
+        const int wv = cand[c].wv16 ? 16 : max_rows / 16;
+        const int lds = lds_bytes_for(backward, max_h, wv, min_rows);
+        if (slice_bytes_for(max_h) > LDS_BUDGET) return 0;
+        const int res = resident_workgroups(backward, wv, lds);
+        static const bool verbose = getenv("DSSVAE_GRU_VERBOSE") != nullptr;
+        if (verbose)
+            fprintf(stderr, "[dssvae gru %s] layout %d: rows %d..%d, %d waves, LDS %d B, grid %d, resident %d\n",
+                    backward ? "bwd" : "fwd", c, min_rows, max_rows, wv, lds, wg, res);
+        if (wg <= res) {
+            *lds_out = lds;
+            return wv;
+        }
     }
     return 0;
 }
@@ -544,7 +725,7 @@ extern "C" int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host,
 extern "C" int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host) {
     if (!n_host || H_max <= 0 || (rows_max != 16 && rows_max != 32 && rows_max != 64 && rows_max != 128))
         return DSSVAE_EINVAL;
-    *n_host = resident_workgroups(backward != 0, rows_max / 16, lds_bytes_for(H_max));
+    *n_host = resident_workgroups(backward != 0, rows_max / 16, slice_bytes_for(H_max));
     return DSSVAE_OK;
 }
 
@@ -565,7 +746,8 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
     int rows[DSSVAE_GRU_MAX_INST];
-    const int wv = pick_rows(false, n_inst, Bs, Hs, want, rows);
+    int lds_bytes = 0;
+    const int wv = pick_rows(false, n_inst, Bs, Hs, want, rows, &lds_bytes);
     if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
     int wg = 0, max_h = 0;
@@ -581,7 +763,6 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
         d.hx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
         if (inst[i].H > max_h) max_h = inst[i].H;
     }
-    const int lds_bytes = lds_bytes_for(max_h);
     hipStream_t s = (hipStream_t)stream;
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
@@ -610,7 +791,8 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
     int rows[DSSVAE_GRU_MAX_INST];
-    const int wv = pick_rows(true, n_inst, Bs, Hs, want, rows);
+    int lds_bytes = 0;
+    const int wv = pick_rows(true, n_inst, Bs, Hs, want, rows, &lds_bytes);
     if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
     int wg = 0, max_h = 0;
@@ -626,7 +808,6 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
         d.gx = reinterpret_cast<float*>(static_cast<char*>(workspace) + L.buf_off[i]);
         if (inst[i].H > max_h) max_h = inst[i].H;
     }
-    const int lds_bytes = lds_bytes_for(max_h);
     hipStream_t s = (hipStream_t)stream;
     const int e = dssvae_zero2d(reinterpret_cast<float*>(workspace), (int64_t)(L.header_bytes / 4), 1,
                                 (int)(L.header_bytes / 4), s);
@@ -637,6 +818,19 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
+
+#ifdef GRU_PROFILE
+extern "C" int dssvae_gru_profile_read(void* dst_host, int64_t bytes) {
+    if (bytes > (int64_t)sizeof(g_prof)) bytes = sizeof(g_prof);
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_prof), (size_t)bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int dssvae_gru_profile_part(void* dst_host) {
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_prof_part), sizeof(g_prof_part), 0, hipMemcpyDeviceToHost);
+}
+extern "C" int dssvae_gru_profile_simd(void* dst_host) {
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_simd), sizeof(g_simd), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int dssvae_gru_check(void* workspace, void* stream) {
     if (!workspace) return DSSVAE_EINVAL;

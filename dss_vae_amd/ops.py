@@ -903,6 +903,26 @@ def _pack(insts):
     return [sorted(l[0]) for l in launches]
 
 
+GRU_SEGMENT_MIN = int(_os.environ.get("DSSVAE_GRU_SEGMENT_MIN", "16"))  # 0 = never cut a launch in time
+
+
+def _segments(Ts):
+    """Cut a persistent launch in time where its recurrences end: [(t0, t1, members)] with members = positions in
+    Ts of the recurrences still running in steps [t0, t1).  Once the short recurrences are over, the long ones
+    continue in a launch of their own -- fewer cells, so the library can give them finer cells with the K range of
+    a step split over more waves (csrc/gru.hip: pick_rows) instead of idling the finished recurrences' CUs.  A cut
+    is made only where at least GRU_SEGMENT_MIN steps remain (it costs a launch boundary)."""
+    cuts, t0 = [], 0
+    ends = sorted(set(Ts))
+    for k, t1 in enumerate(ends):
+        last = k == len(ends) - 1
+        if not last and (GRU_SEGMENT_MIN <= 0 or ends[-1] - t1 < GRU_SEGMENT_MIN or t1 - t0 < GRU_SEGMENT_MIN):
+            continue
+        cuts.append((t0, t1, [j for j, T in enumerate(Ts) if T > t0]))
+        t0 = t1
+    return cuts
+
+
 _PERSISTENT_ERR = {}
 
 
@@ -1018,27 +1038,33 @@ class _GruFn(Function):
                                hl[i], gates[i])
         pers = [i for i in range(n) if fit[i]]
         for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in pers]):
-            launch = [pers[k] for k in launch_]
-            arr = (L.GruFwdInst * len(launch))()
-            for k, i in enumerate(launch):
-                o = outs[meta["group"][i]]
-                assert (o.size(0), o.size(1)) == BT[i]
-                arr[k] = L.GruFwdInst(
-                    xs[i].data_ptr(), _xproj_ld(xs[i]), ws[i].data_ptr(), bs[i].data_ptr(),
-                    None if h0s[i] is None else h0s[i].data_ptr(),
-                    None if lengths is None else lengths.data_ptr(),
-                    o.data_ptr() + 4 * meta["col"][i], o.size(2), hl[i].data_ptr(),
-                    None if gates[i] is None else gates[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
-                    int(meta["reverse"][i]))
-            wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
-            fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
-            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * (9 if save[i] else 4) for i in launch)
-            with _PersistentTurn(dev), _Span("gru_fwd_kernel", fl, by, max(BT[i][1] for i in launch),
-                                             detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
-                L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
-            _note_persistent_error(wsb)
-            if meta.get("check"):
-                L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
+            whole = [pers[k] for k in launch_]
+            for t0, t1, members in _segments([BT[i][1] for i in whole]):
+                launch = [whole[j] for j in members]
+                arr = (L.GruFwdInst * len(launch))()
+                for k, i in enumerate(launch):
+                    o = outs[meta["group"][i]]
+                    assert (o.size(0), o.size(1)) == BT[i]
+                    # a later segment continues from the state the previous one left in hl[i] (read and written
+                    # by the same lane: in place); a recurrence that ends inside the segment stops at its own T
+                    state = h0s[i] if t0 == 0 else hl[i]
+                    arr[k] = L.GruFwdInst(
+                        xs[i].data_ptr(), _xproj_ld(xs[i]), ws[i].data_ptr(), bs[i].data_ptr(),
+                        None if state is None else state.data_ptr(),
+                        None if lengths is None else lengths.data_ptr(),
+                        o.data_ptr() + 4 * meta["col"][i], o.size(2), hl[i].data_ptr(),
+                        None if gates[i] is None else gates[i].data_ptr(), BT[i][0], min(t1, BT[i][1]) - t0, Hs[i],
+                        int(meta["reverse"][i]), t0, BT[i][1])
+                wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
+                steps = [min(t1, BT[i][1]) - t0 for i in launch]
+                fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
+                by = sum(4.0 * BT[i][0] * n_t * Hs[i] * (9 if save[i] else 4) for i, n_t in zip(launch, steps))
+                with _PersistentTurn(dev), _Span("gru_fwd_kernel", fl, by, max(steps), detail=" ".join(
+                        "B%dT%dH%d" % (BT[i][0], n_t, Hs[i]) for i, n_t in zip(launch, steps))):
+                    L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
+                _note_persistent_error(wsb)
+                if meta.get("check"):
+                    L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
         ctx.bias_refs = (list(tensors[2::5]), list(tensors[4::5]))  # identify the parameters for _claim
         ctx.h0_none = [h is None for h in h0s]
@@ -1092,26 +1118,31 @@ class _GruFn(Function):
                     colsum(dgh[i].view(rows, 3 * Hs[i]), out=dbh[i])
         live_p = [i for i in live if ctx.fit[i]]
         for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live_p]):
-            launch = [live_p[k] for k in launch_]
-            arr = (L.GruBwdInst * len(launch))()
-            for k, i in enumerate(launch):
-                do = douts[meta["group"][i]]
-                arr[k] = L.GruBwdInst(
-                    ws[i].data_ptr(), None, None if lengths is None else lengths.data_ptr(), None, 0,
-                    gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
-                    0 if do is None else do.size(2), None if dhl[i] is None else dhl[i].data_ptr(),
-                    dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], BT[i][1], Hs[i],
-                    int(meta["reverse"][i]), None if dbx[i] is None else dbx[i].data_ptr(),
-                    None if dbh[i] is None else dbh[i].data_ptr())
-            wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
-            fl = sum(6.0 * BT[i][0] * BT[i][1] * Hs[i] * Hs[i] for i in launch)
-            by = sum(4.0 * BT[i][0] * BT[i][1] * Hs[i] * 12 for i in launch)
-            with _PersistentTurn(dev), _Span("gru_bwd_kernel", fl, by, max(BT[i][1] for i in launch),
-                                             detail=" ".join("B%dT%dH%d" % (BT[i][0], BT[i][1], Hs[i]) for i in launch)):
-                L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
-            _note_persistent_error(wsb)
-            if meta.get("check"):
-                L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
+            whole = [live_p[k] for k in launch_]
+            # the forward's segments, last first: d(state) entering a segment is what the later one left in dh0[i]
+            for t0, t1, members in reversed(_segments([BT[i][1] for i in whole])):
+                launch = [whole[j] for j in members]
+                arr = (L.GruBwdInst * len(launch))()
+                for k, i in enumerate(launch):
+                    do = douts[meta["group"][i]]
+                    dstate = dhl[i] if t1 >= BT[i][1] else dh0[i]
+                    arr[k] = L.GruBwdInst(
+                        ws[i].data_ptr(), None, None if lengths is None else lengths.data_ptr(), None, 0,
+                        gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
+                        0 if do is None else do.size(2), None if dstate is None else dstate.data_ptr(),
+                        dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], min(t1, BT[i][1]) - t0,
+                        Hs[i], int(meta["reverse"][i]), None if dbx[i] is None else dbx[i].data_ptr(),
+                        None if dbh[i] is None else dbh[i].data_ptr(), t0, BT[i][1])
+                wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
+                steps = [min(t1, BT[i][1]) - t0 for i in launch]
+                fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
+                by = sum(4.0 * BT[i][0] * n_t * Hs[i] * 12 for i, n_t in zip(launch, steps))
+                with _PersistentTurn(dev), _Span("gru_bwd_kernel", fl, by, max(steps), detail=" ".join(
+                        "B%dT%dH%d" % (BT[i][0], n_t, Hs[i]) for i, n_t in zip(launch, steps))):
+                    L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
+                _note_persistent_error(wsb)
+                if meta.get("check"):
+                    L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         # recurrent weight gradients dW_hh = dgh^T . h_{t-1} of all instances in grouped launches
         iw = [i for i in range(n) if dgx[i] is not None and ctx.needs_input_grad[2 + 5 * i]]
         pairs = []

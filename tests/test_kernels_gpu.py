@@ -219,16 +219,21 @@ def gru_reference(x, h0, wih, whh, bih, bhh, lengths, reverse):
 
 
 @pytest.mark.parametrize("B,T,H,I,packed", [(3, 4, 8, 5, False), (70, 6, 30, 12, True), (64, 9, 150, 20, True),
-                                            (130, 5, 300, 16, False), (256, 4, 600, 8, False)])
-@pytest.mark.parametrize("stepwise", [False, True, "waves8"])
+                                            (130, 5, 300, 16, False), (256, 4, 600, 8, False),
+                                            (1030, 3, 300, 8, True)])
+@pytest.mark.parametrize("stepwise", [False, True, "waves8", "nosplit"])
 def test_persistent_gru_forward_backward(B, T, H, I, packed, stepwise, monkeypatch):
     """two instances (forward + reverse direction) in one persistent launch -- or, stepwise=True, down the
     per-timestep GEMM + gate-kernel path that oversized recurrences take; "waves8": the persistent kernel
-    with 128-row workgroups (what a launch that does not fit one 64-row cell per CU uses) -- vs explicit
-    equations"""
+    with 128-row workgroups of 8 waves; "nosplit": the layouts without the K split inside a workgroup (what a grid
+    that is not resident in 16-wave workgroups falls back to); the default (False) takes the 16-wave workgroups:
+    4 row groups x 4 K parts, or 8 x 2 at B = 1030 -- vs explicit equations"""
     from dss_vae_amd import ops
     if stepwise == "waves8":
         monkeypatch.setenv("DSSVAE_GRU_WAVES", "8")
+        stepwise = False
+    if stepwise == "nosplit":
+        monkeypatch.setenv("DSSVAE_GRU_KSPLIT", "0")
         stepwise = False
     monkeypatch.setattr(ops, "FORCE_STEPWISE_GRU", stepwise)
     g = torch.Generator().manual_seed(B + H)
@@ -276,6 +281,95 @@ def test_persistent_gru_forward_backward(B, T, H, I, packed, stepwise, monkeypat
     for d in range(2):
         for name, a, r in zip(("dwih", "dwhh", "dbih", "dbhh", "dh0"), dl[d], leaves[d]):
             close(a.grad, r.grad, rtol=1e-4, atol=1e-4, what="%s[%d]" % (name, d))
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_persistent_gru_launch_cut_in_time(reverse, monkeypatch):
+    """recurrences of different lengths in one gru_layer call: the launch is cut where the short ones end and the
+    long ones continue in a launch of their own from the handed-over state (ops._segments); results and gradients
+    equal the explicit equations, and equal the uncut launch"""
+    from dss_vae_amd import ops
+    import oracle
+    B, shapes = 70, [(40, 30), (12, 50), (40, 16), (13, 30)]  # (T, H) per recurrence
+    monkeypatch.setattr(ops, "GRU_SEGMENT_MIN", 8)
+    # the T = 13 recurrence ends one step into the second segment: too short a piece for a cut of its own
+    assert [(a, b) for a, b, _ in ops._segments([t for t, _ in shapes])] == [(0, 12), (12, 40)]
+    ps = [[rnd(B, T, 3 * H, seed=i), rnd(3 * H, H, seed=10 + i, scale=0.3), rnd(3 * H, seed=20 + i, scale=0.3),
+           rnd(B, H, seed=30 + i)] for i, (T, H) in enumerate(shapes)]
+    gos = [rnd(B, T, H, seed=40 + i) for i, (T, H) in enumerate(shapes)]
+    ghs = [rnd(B, H, seed=50 + i) for i, (T, H) in enumerate(shapes)]
+
+    def run(seg_min):
+        monkeypatch.setattr(ops, "GRU_SEGMENT_MIN", seg_min)
+        dl = [[t.clone().to(DEV).requires_grad_(True) for t in p] for p in ps]
+        insts = [dict(xproj=x, whh=whh, bhh=bhh, h0=h0, reverse=reverse, group=i, col=0)
+                 for i, (x, whh, bhh, h0) in enumerate(dl)]
+        outs, hl = ops.gru_layer(insts, check=True)
+        sum((o * g.to(DEV)).sum() + (h * gh.to(DEV)).sum() for o, h, g, gh in zip(outs, hl, gos, ghs)).backward()
+        return outs, hl, dl
+
+    outs, hl, dl = run(8)
+    outs_u, hl_u, dl_u = run(0)
+    for i, (T, H) in enumerate(shapes):
+        leaves = [t.clone().double().requires_grad_(True) for t in ps[i]]
+        x, whh, bhh, h0 = leaves
+        o, h = oracle.gru_loop(x, h0, torch.eye(3 * H, dtype=torch.float64), whh, torch.zeros(3 * H, dtype=torch.float64),
+                               bhh, reverse=reverse)
+        ((o * gos[i].double()).sum() + (h * ghs[i].double()).sum()).backward()
+        close(outs[i], o, what="out%d" % i)
+        close(hl[i], h, what="h_last%d" % i)
+        for name, a, r, u in zip(("dxproj", "dwhh", "dbhh", "dh0"), dl[i], leaves, dl_u[i]):
+            close(a.grad, r.grad, rtol=1e-4, atol=1e-4, what="%s[%d]" % (name, i))
+            close(a.grad, u.grad, rtol=1e-5, atol=1e-5, what="%s[%d] cut vs uncut" % (name, i))
+        close(outs[i], outs_u[i], rtol=1e-6, atol=1e-6, what="out%d cut vs uncut" % i)
+
+
+def test_persistent_gru_grid_one_over_the_residency_bound_is_refused():
+    """every workgroup of a persistent launch spins on its peers, so the library admits a grid only up to what the
+    chip holds at once (the occupancy answer x CUs: dssvae_gru_resident_workgroups): a grid of exactly that many
+    workgroups runs, one more returns DSSVAE_ETOOBIG before anything is launched"""
+    import ctypes as C
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    n = C.c_int(0)
+    H = 600  # a 114 KB slice: one workgroup per CU, and no room for the K-split layouts' LDS beside it
+    L.check(lib.dssvae_gru_resident_workgroups(H, 128, 0, C.byref(n)), "resident")
+    n = n.value
+    ns = (H + 15) // 16
+    assert n >= ns
+    full, rest = divmod(n, ns)
+
+    def launch(extra):
+        # `full` 128-row batch blocks of H = 600 (ns workgroups each) + one 128-row block of a narrower recurrence
+        shapes = [(128 * full, H)]
+        if rest + extra > 0:
+            shapes.append((128, 16 * (rest + extra)))
+        T = 2
+        keep, insts = [], (L.GruFwdInst * len(shapes))()
+        for i, (B, h) in enumerate(shapes):
+            x = rnd(B, T, 3 * h, seed=i).to(DEV)
+            whh, bhh = rnd(3 * h, h, seed=9 + i, scale=0.05).to(DEV), rnd(3 * h, seed=5).to(DEV)
+            out = torch.empty(B, T, h, device=DEV)
+            keep += [x, whh, bhh, out]
+            it = insts[i]
+            it.xproj, it.ldx, it.whh, it.bhh, it.out, it.ldo = x.data_ptr(), 3 * h, whh.data_ptr(), bhh.data_ptr(), \
+                out.data_ptr(), h
+            it.B, it.T, it.H, it.rows = B, T, h, 128
+        Bs = (C.c_int32 * len(shapes))(*[b for b, _ in shapes])
+        Hs = (C.c_int32 * len(shapes))(*[h for _, h in shapes])
+        nbytes = lib.dssvae_gru_workspace_bytes(len(shapes), Bs, Hs)
+        ws = torch.zeros(nbytes, dtype=torch.uint8, device=DEV)
+        rc = lib.dssvae_gru_fwd(insts, len(shapes), ws.data_ptr(), nbytes, L.stream())
+        if rc == 0:
+            L.check(lib.dssvae_gru_check(ws.data_ptr(), L.stream()), "gru_check")
+            import oracle
+            x, whh, bhh, out = keep[0].cpu(), keep[1].cpu(), keep[2].cpu(), keep[3]
+            o, _ = oracle.gru_loop(x[:4], torch.zeros(4, H), torch.eye(3 * H), whh, torch.zeros(3 * H), bhh)
+            close(out[:4], o, rtol=1e-4, atol=1e-4, what="rows of the full grid")
+        return rc
+
+    assert launch(0) == 0
+    assert launch(1) == L.E_TOOBIG
 
 
 def test_gru_cell_and_no_h0():
