@@ -967,20 +967,41 @@ int launch_store(const OpA& a, const OpB& b, float* C, int64_t ldc, const float*
     return DSSVAE_OK;
 }
 
+thread_local int g_last_store_launches = 1;  // gemm_store_kernel launches of this thread's last store-GEMM call
+
 template <bool TA, bool TB, int VW, bool XF = false>
 int launch_store_tile(const OpA& a, const OpB& b, float* C, int64_t ldc, const float* bias, int M, int N, int K,
                       float alpha, float beta, int ksplit, hipStream_t s) {
     // tile width (128x128 or 128x64) by the cost model above
+    g_last_store_launches = 1;
     const bool may_split = (beta == 0.f || beta == 1.f) && ksplit <= 0;
-    bool narrow = plan_store(M, N, K, 64, may_split).cost < plan_store(M, N, K, 128, may_split).cost;
-    const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width
+    const float c64 = plan_store(M, N, K, 64, may_split).cost, c128 = plan_store(M, N, K, 128, may_split).cost;
+    bool narrow = c64 < c128;
+    const int force = tune_env("DSSVAE_GEMM_TILE", 0);  // development knob: 64 / 128 force the tile width, 1 = no mixing
     if (force == 64) narrow = true;
     if (force == 128) narrow = false;
+    // Mixed widths: when the last 128-wide tile column would be at most half full (N = 904 = 7 x 128 + 8: the
+    // CE wgrad; N = 300 = 2 x 128 + 44: its dgrad), the full tile columns go to the 128x128 kernel and the
+    // remainder to the 128x64 kernel as a GEMM of its own on the same A (disjoint columns of C): 7.5 tile columns'
+    // worth of work instead of 8, 2.5 instead of 3 (or 5 narrow ones).
+    const int rem = N % 128, n_main = N - rem;
+    if (force == 0 && n_main > 0 && rem > 0 && rem <= 64 &&
+        plan_store(M, n_main, K, 128, may_split).cost + plan_store(M, rem, K, 64, may_split).cost < fminf(c64, c128)) {
+        const int e = launch_store<TA, TB, VW, 2, 2, XF>(a, b, C, ldc, bias, M, n_main, K, alpha, beta, ksplit, s);
+        if (e != DSSVAE_OK) return e;
+        g_last_store_launches = 2;
+        OpB b2 = b;
+        b2.p += TB ? (int64_t)n_main : (int64_t)n_main * b.ld;
+        return launch_store<TA, TB, VW, 2, 1, XF>(a, b2, C + n_main, ldc, bias ? bias + n_main : nullptr, M, rem, K,
+                                                  alpha, beta, ksplit, s);
+    }
     if (narrow) return launch_store<TA, TB, VW, 2, 1, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
     return launch_store<TA, TB, VW, 2, 2, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, ksplit, s);
 }
 
 }  // namespace
+
+extern "C" int dssvae_gemm_last_launches(void) { return g_last_store_launches; }
 
 extern "C" int dssvae_gemm_f32(const float* A, int64_t lda, int trans_a, const int64_t* a_rows, const float* B,
                                int64_t ldb, int trans_b, float* C, int64_t ldc, const float* bias, int M, int N,

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 3  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 4  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -62,6 +62,7 @@ _P, _I, _L, _F, _U64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 _SIGNATURES = {
     "dssvae_abi_version": ([], _I),
     "dssvae_device_cus": ([C.POINTER(C.c_int)], _I),
+    "dssvae_gemm_last_launches": ([], _I),
     "dssvae_gemm_f32": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _P], _I),
     "dssvae_gemm_f32_splitk": ([_P, _L, _I, _P, _P, _L, _I, _P, _L, _P, _I, _I, _I, _F, _F, _I, _P], _I),
     "dssvae_gemm_f32_grouped": ([C.POINTER(GemmProblem), _I, _I, _I, _P], _I),

@@ -21,9 +21,9 @@ class KernelTimer(object):
     def summary(self):
         """-> {kernel: dict(launches, total_ms, avg_ms, flops, bytes)}; call after a device sync."""
         out = {}
-        for name, e0, e1, fl, by, st, _detail in self.spans:
+        for name, e0, e1, fl, by, st, _detail, launches in self.spans:
             d = out.setdefault(name, dict(launches=0, total_ms=0.0, flops=0.0, bytes=0.0, timesteps=0))
-            d["launches"] += 1
+            d["launches"] += launches
             d["total_ms"] += e0.elapsed_time(e1)
             d["flops"] += fl
             d["bytes"] += by
@@ -35,7 +35,7 @@ class KernelTimer(object):
     def by_shape(self):
         """-> [(kernel, shape string, launches, total_ms, TFLOP/s)] sorted by time (development aid)."""
         out = {}
-        for name, e0, e1, fl, by, st, detail in self.spans:
+        for name, e0, e1, fl, by, st, detail, _launches in self.spans:
             d = out.setdefault((name, detail), [0, 0.0, 0.0])
             d[0] += 1
             d[1] += e0.elapsed_time(e1)
@@ -48,10 +48,11 @@ PROFILE = None
 
 
 class _Span(object):
-    __slots__ = ("name", "flops", "bytes", "e0", "steps", "detail")
+    __slots__ = ("name", "flops", "bytes", "e0", "steps", "detail", "launches")
 
     def __init__(self, name, flops, nbytes, steps=0, detail=None):
         self.name, self.flops, self.bytes, self.steps, self.detail = name, flops, nbytes, steps, detail
+        self.launches = 1  # launches of the named kernel inside the span (a store GEMM may run as two: set by the caller)
 
     def __enter__(self):
         if PROFILE is not None:
@@ -64,7 +65,7 @@ class _Span(object):
             e1 = torch.cuda.Event(enable_timing=True)
             e1.record()
             PROFILE.spans.append((self.name, self.e0, e1, float(self.flops), float(self.bytes), int(self.steps),
-                                  self.detail))
+                                  self.detail, int(self.launches)))
         return False
 
 
@@ -109,9 +110,11 @@ def _rows(t):
 def _gemm(A, lda, ta, B, ldb, tb, Cm, ldc, bias, M, N, K, alpha=1.0, beta=0.0, a_rows=None):
     L.require_cuda(A, B, Cm)
     with _Span("gemm_store_kernel", 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N),
-               detail="%s%s M=%d N=%d K=%d%s" % ("t" if ta else "n", "n" if tb else "t", M, N, K, " +=" if beta else "")):
+               detail="%s%s M=%d N=%d K=%d%s" % ("t" if ta else "n", "n" if tb else "t", M, N, K, " +=" if beta else "")) as sp:
         L.check(L.load().dssvae_gemm_f32(L.ptr(A), lda, int(ta), L.ptr(a_rows), L.ptr(B), ldb, int(tb), L.ptr(Cm),
                                          ldc, L.ptr(bias), M, N, K, alpha, beta, L.stream()), "dssvae_gemm_f32")
+        if PROFILE is not None:
+            sp.launches = L.load().dssvae_gemm_last_launches()
 
 
 def mm_nt(x, w, bias=None, out=None, beta=0.0):
@@ -216,10 +219,12 @@ def _gemm_dlogits(slab, ldl, rows, cols, rowinfo, trans_a, B, ldb, Cm, ldc, N, b
     """C (+)= dlogits(slab) . B or dlogits(slab)^T . B with the softmax gradient applied while the slab is staged"""
     M_, K_ = (cols, rows) if trans_a else (rows, cols)
     with _Span("gemm_store_kernel", 2.0 * M_ * N * K_, 4.0 * (M_ * K_ + N * K_ + M_ * N),
-               detail="%s dlogits M=%d N=%d K=%d%s" % ("tn" if trans_a else "nn", M_, N, K_, " +=" if beta else "")):
+               detail="%s dlogits M=%d N=%d K=%d%s" % ("tn" if trans_a else "nn", M_, N, K_, " +=" if beta else "")) as sp:
         L.check(L.load().dssvae_gemm_f32_dlogits(L.ptr(slab), ldl, rows, cols, L.ptr(rowinfo), int(trans_a), L.ptr(B),
                                                  ldb, L.ptr(Cm), ldc, N, float(beta), L.stream()),
                 "dssvae_gemm_f32_dlogits")
+        if PROFILE is not None:
+            sp.launches = L.load().dssvae_gemm_last_launches()
 
 
 _ONES_COL = {}

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 3 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step */
+#define DSSVAE_ABI_VERSION 4 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -50,6 +50,11 @@ int dssvae_gemm_f32(const float* A, int64_t lda, int trans_a, const int64_t* a_r
  * combined with fp32 atomic adds; needs beta in {0,1}; ksplit <= 0: chosen from the tile count so
  * that small-M/N, large-K products -- the dgrad/wgrad shapes of the vocabulary projection and the
  * GRU weight gradients -- still fill the chip).  dssvae_gemm_f32 is ksplit = 0. */
+/* How many gemm_store_kernel launches the calling thread's last dssvae_gemm_f32* / dssvae_gemm_f32_dlogits call made:
+ * 1, or 2 when the output's last 128-wide tile column would have been at most half full and the call ran the full
+ * tile columns and the remainder as two launches (profilers divide an entry point's time by this; no reference
+ * counterpart). */
+int dssvae_gemm_last_launches(void);
 int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, const int64_t* a_rows,
                            const float* B, int64_t ldb, int trans_b,
                            float* C, int64_t ldc, const float* bias,
