@@ -62,7 +62,8 @@ struct FwdDev {
 struct FwdArgs {
     FwdDev inst[DSSVAE_GRU_MAX_INST];
     int n_inst;
-    unsigned* err;
+    unsigned* err;     // error word of this launch (first word of its workspace)
+    unsigned* sticky;  // the device's registered error word (dssvae_gru_error_word), or NULL
 };
 struct BwdDev {
     dssvae_gru_bwd_inst in;
@@ -74,7 +75,16 @@ struct BwdArgs {
     BwdDev inst[DSSVAE_GRU_MAX_INST];
     int n_inst;
     unsigned* err;
+    unsigned* sticky;
 };
+struct ErrWords {
+    unsigned* err;
+    unsigned* sticky;
+};
+__device__ __forceinline__ void raise_timeout(ErrWords e) {
+    __hip_atomic_store(e.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e.sticky) __hip_atomic_store(e.sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
@@ -98,15 +108,15 @@ __device__ __forceinline__ void publish(unsigned* cnt) {
 }
 
 // lane 0 polls (sc1 loads) while the rest of the wave is masked off; the payload loads that follow are all sc1
-__device__ __forceinline__ void await(unsigned* cnt, unsigned target, unsigned* err) {
+__device__ __forceinline__ void await(unsigned* cnt, unsigned target, ErrWords err) {
     if ((threadIdx.x & 63) == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(0);
             if ((++spins & 1023u) == 0) {
                 if (spins > SPIN_LIMIT ||
-                    __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_load(err.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    raise_timeout(err);
                     break;
                 }
             }
@@ -125,13 +135,13 @@ __device__ __forceinline__ void lds_signal(lds_word* w, unsigned v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // what this wave wrote to LDS before is there
     *w = v;
 }
-__device__ __forceinline__ void lds_await(lds_word* w, unsigned target, unsigned* err) {
+__device__ __forceinline__ void lds_await(lds_word* w, unsigned target, ErrWords err) {
     unsigned spins = 0;
     while (*w < target) {
         __builtin_amdgcn_s_sleep(0);
         if ((++spins & 4095u) == 0 &&
-            (spins > SPIN_LIMIT || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
-            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            (spins > SPIN_LIMIT || __hip_atomic_load(err.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
+            raise_timeout(err);
             break;
         }
     }
@@ -298,12 +308,12 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             load4(xr, xp + ub, vec_x, n_ok);
             load4(xz, xp + H + ub, vec_x, n_ok);
             load4(xn, xp + 2 * H + ub, vec_x, n_ok);
-            await(cnt, (unsigned)(step + 1) * NS, args.err);
+            await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             PROF(1);
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
         } else {
             PROFP(0);
-            lds_await(go, (unsigned)step + 1u, args.err);
+            lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
             PROFP(1);
         }
 
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 #endif
         PROF(2);
         for (int p = 1; p < KS; ++p) {
-            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, args.err);
+            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
 #ifdef GRU_PROFILE
             if (p == 1) PROF(7);
 #endif
@@ -507,10 +517,10 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                 store4(ox, dgr, vec_h, n_ok); store4(ox + H, dgz, vec_h, n_ok); store4(ox + 2 * H, dgn, vec_h, n_ok);
                 store4(oh, dgr, vec_h, n_ok); store4(oh + H, dgz, vec_h, n_ok); store4(oh + 2 * H, dgm, vec_h, n_ok);
             }
-            await(cnt, (unsigned)(step + 1) * NS, args.err);
+            await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
         } else {
-            lds_await(go, (unsigned)step + 1u, args.err);
+            lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
         }
 
         f32x4 acc[3];
@@ -543,7 +553,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             continue;
         }
         for (int p = 1; p < KS; ++p) {
-            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, args.err);
+            lds_await(sync + 32 + rg * KS + (p + rg % KS) % KS, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
             sum += parts[(slot0 + p - 1) * 64 + lane];
         }
 #pragma unroll
@@ -713,7 +723,24 @@ int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, con
     return 0;
 }
 
+// the error word registered for the current device (dssvae_gru_error_word), or NULL
+unsigned* g_sticky[64];
+unsigned* sticky_word() {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return g_sticky[dev];
+}
+
 }  // namespace
+
+extern "C" int dssvae_gru_error_word(void* word) {
+    int dev = -1;
+    const hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return DSSVAE_EINVAL;
+    g_sticky[dev] = static_cast<unsigned*>(word);
+    return DSSVAE_OK;
+}
 
 extern "C" int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host) {
     if (n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !B_host || !H_host) return DSSVAE_EINVAL;
@@ -745,6 +772,7 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     FwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
+    args.sticky = sticky_word();
     int rows[DSSVAE_GRU_MAX_INST];
     int lds_bytes = 0;
     const int wv = pick_rows(false, n_inst, Bs, Hs, want, rows, &lds_bytes);
@@ -790,6 +818,7 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     BwdArgs args;
     args.n_inst = n_inst;
     args.err = reinterpret_cast<unsigned*>(workspace);
+    args.sticky = sticky_word();
     int rows[DSSVAE_GRU_MAX_INST];
     int lds_bytes = 0;
     const int wv = pick_rows(true, n_inst, Bs, Hs, want, rows, &lds_bytes);

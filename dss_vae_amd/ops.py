@@ -939,6 +939,9 @@ def persistent_error_word(device):
     if key not in _PERSISTENT_ERR:
         _PERSISTENT_ERR[key] = torch.zeros(1, device=torch.device("cuda", key), dtype=torch.int32)
         torch.cuda.current_stream().synchronize()  # once: every stream may use the word from now on
+        # the library's persistent kernels raise it themselves from now on (no fold-in launch per recurrence)
+        with torch.cuda.device(key):
+            L.check(L.load().dssvae_gru_error_word(_PERSISTENT_ERR[key].data_ptr()), "dssvae_gru_error_word")
     return _PERSISTENT_ERR[key]
 
 
@@ -946,15 +949,11 @@ _ZERO_IDX = {}
 
 
 def _note_persistent_error(wsb):
-    """fold the launch's error word (first int32 of its workspace: a bounded spin gave up) into a sticky
-    per-device counter, on the stream and without a host sync; `check_persistent_errors` reads it, and the
-    optimiser's update kernel reads it on device (a timed-out step never reaches the parameters).  The add is
-    atomic (index_add_): persistent launches of different streams may report at the same time."""
-    dev = wsb.device
-    if dev not in _ZERO_IDX:
-        _ZERO_IDX[dev] = torch.zeros(1, device=dev, dtype=torch.int64)
-        torch.cuda.current_stream().synchronize()  # once: every stream may use it from now on
-    persistent_error_word(dev).index_add_(0, _ZERO_IDX[dev], wsb[:4].view(torch.int32))
+    """make sure the device's sticky error word exists and is registered with the library BEFORE the launch: a
+    persistent kernel whose bounded spin gives up sets it (besides the first int32 of its own workspace), without
+    a host sync; `check_persistent_errors` reads it, and the optimiser's update kernel reads it on device (a
+    timed-out step never reaches the parameters)."""
+    persistent_error_word(wsb.device)
 
 
 # Persistent launches never overlap EACH OTHER, whatever streams they are on: two partly resident grids can starve
@@ -988,8 +987,8 @@ def check_persistent_errors():
         n = int(t.item())
         if n:
             t.zero_()
-            raise RuntimeError("%d persistent GRU launch(es) on device %s gave up waiting for a peer workgroup "
-                               "(DSSVAE_ETIMEOUT): the grid was not co-resident" % (n, key))
+            raise RuntimeError("a persistent GRU launch on device %s gave up waiting for a peer workgroup "
+                               "(DSSVAE_ETIMEOUT) since the last check: the grid was not co-resident" % (key,))
 
 
 def _workspace(Bs, Hs, dev):
@@ -1061,13 +1060,13 @@ class _GruFn(Function):
                         None if gates[i] is None else gates[i].data_ptr(), BT[i][0], min(t1, BT[i][1]) - t0, Hs[i],
                         int(meta["reverse"][i]), t0, BT[i][1])
                 wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
+                _note_persistent_error(wsb)
                 steps = [min(t1, BT[i][1]) - t0 for i in launch]
                 fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
                 by = sum(4.0 * BT[i][0] * n_t * Hs[i] * (9 if save[i] else 4) for i, n_t in zip(launch, steps))
                 with _PersistentTurn(dev), _Span("gru_fwd_kernel", fl, by, max(steps), detail=" ".join(
                         "B%dT%dH%d" % (BT[i][0], n_t, Hs[i]) for i, n_t in zip(launch, steps))):
                     L.check(lib.dssvae_gru_fwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd")
-                _note_persistent_error(wsb)
                 if meta.get("check"):
                     L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_fwd (persistent sync)")
         ctx.meta, ctx.Hs, ctx.BT = meta, Hs, BT
@@ -1139,13 +1138,13 @@ class _GruFn(Function):
                         Hs[i], int(meta["reverse"][i]), None if dbx[i] is None else dbx[i].data_ptr(),
                         None if dbh[i] is None else dbh[i].data_ptr(), t0, BT[i][1])
                 wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
+                _note_persistent_error(wsb)
                 steps = [min(t1, BT[i][1]) - t0 for i in launch]
                 fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
                 by = sum(4.0 * BT[i][0] * n_t * Hs[i] * 12 for i, n_t in zip(launch, steps))
                 with _PersistentTurn(dev), _Span("gru_bwd_kernel", fl, by, max(steps), detail=" ".join(
                         "B%dT%dH%d" % (BT[i][0], n_t, Hs[i]) for i, n_t in zip(launch, steps))):
                     L.check(lib.dssvae_gru_bwd(arr, len(launch), L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd")
-                _note_persistent_error(wsb)
                 if meta.get("check"):
                     L.check(lib.dssvae_gru_check(L.ptr(wsb), L.stream()), "dssvae_gru_bwd (persistent sync)")
         # recurrent weight gradients dW_hh = dgh^T . h_{t-1} of all instances in grouped launches

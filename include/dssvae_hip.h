@@ -257,6 +257,11 @@ int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst_host, int n_inst, void* works
                    int64_t workspace_bytes, void* stream);
 int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst_host, int n_inst, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* Registers (word != NULL) or clears (NULL) a device int32 for the CURRENT device that every later persistent launch on
+ * it sets to 1 when one of its bounded spins gives up, besides the launch's own error word: one sticky word for many
+ * launches, readable on the device (dssvae_adam_step's skip_flag) or by the host, instead of a fold-in kernel behind
+ * every launch.  The caller owns the memory and keeps it alive while registered.  No reference counterpart. */
+int dssvae_gru_error_word(void* word);
 /* Reads the error word a persistent launch leaves in its workspace (synchronises the stream). */
 int dssvae_gru_check(void* workspace, void* stream);
 
