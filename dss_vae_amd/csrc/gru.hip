@@ -214,10 +214,13 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, in
 // ------------------------------------------------------------------------------------------
 // WV waves per workgroup: 4 (64 batch rows) or 8 (128 rows: half the workgroups per recurrence, two waves per
 // SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
-template <int WV>
+// LSTM = true: the same kernel for an LSTM cell (gate order i, f, g, o; 4 gate rows per unit in the slice, the cell
+// state beside the hidden state in registers; saved row [i | f | g | o | c_{t-1} | h_{t-1} | tanh c_t], 7H wide)
+template <int WV, bool LSTM>
 __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     constexpr int NTHR = 64 * WV;
-    constexpr int CHF = WV > 8 ? 5 : CH;
+    constexpr int NG = LSTM ? 4 : 3;
+    constexpr int CHF = WV > 8 ? (LSTM ? 3 : 5) : CH;
     // Ws[g][slice s][c][kq][j] = whh[(g*H + u0 + j)*H + 16 s + 4 kq + c]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
@@ -245,11 +248,11 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     const bool vec_h = (H % 4) == 0;
     const int gate_stride = NS * 256;
     // behind the slice, only there (and touched) when KS > 1: a slot of partial sums per non-lead wave, sync words
-    f32x4* parts = reinterpret_cast<f32x4*>(Ws + 3 * NS * 256);
-    lds_word* sync = (lds_word*)(parts + (WV - WVI) * 3 * 64);
+    f32x4* parts = reinterpret_cast<f32x4*>(Ws + NG * NS * 256);
+    lds_word* sync = (lds_word*)(parts + (WV - WVI) * NG * 64);
     const int slot0 = rg * (KS - 1);  // first slot of this row group's non-lead waves
 
-    for (int idx = threadIdx.x; idx < 3 * NS * 256; idx += NTHR) {
+    for (int idx = threadIdx.x; idx < NG * NS * 256; idx += NTHR) {
         const int g = idx / (NS * 256), rem = idx % (NS * 256);
         const int jj = rem / (NS * 16), k = rem % (NS * 16);  // k fastest: coalesced global reads
         const int u = u0 + jj;
@@ -258,9 +261,9 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         Ws[g * gate_stride + s * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + jj] = w;
     }
     if (KS > 1 && threadIdx.x < SYNC_WORDS) sync[threadIdx.x] = 0u;
-    float bh[3][4];
+    float bh[NG][4];
 #pragma unroll
-    for (int g = 0; g < 3; ++g)
+    for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int c = 0; c < 4; ++c) bh[g][c] = (c < n_ok) ? in.bhh[g * H + ub + c] : 0.f;
     const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
@@ -281,9 +284,10 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 
     __syncthreads();  // the slice is in LDS for every wave; from here on the waves run free
     // state 0 into the exchange buffer (pad units and pad rows are zero and stay zero)
-    float hcur[4] = {0.f, 0.f, 0.f, 0.f};
+    float hcur[4] = {0.f, 0.f, 0.f, 0.f}, ccur[4] = {0.f, 0.f, 0.f, 0.f};
     if (lead) {
         if (row_ok && in.h0) load4(hcur, in.h0 + (size_t)b * H + ub, vec_h, n_ok);
+        if (LSTM && row_ok && in.c0) load4(ccur, in.c0 + (size_t)b * H + ub, vec_h, n_ok);
         st_sc1((f32x4){hcur[0], hcur[1], hcur[2], hcur[3]}, ws0, voff, own);
         publish(cnt);
     }
@@ -301,13 +305,12 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         const __amdgpu_buffer_rsrc_t rin = (step & 1) ? rs1 : rs0, rout = (step & 1) ? ws0 : ws1;
         // the x-projection gates of this step do not depend on the hand-off: fetch them first
         const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
-        float xr[4], xz[4], xn[4];
+        float xg[NG][4];
         if (lead) {
             const float* xp = in.xproj + bt * in.ldx;
             const bool vec_x = vec_h && (in.ldx % 4) == 0;
-            load4(xr, xp + ub, vec_x, n_ok);
-            load4(xz, xp + H + ub, vec_x, n_ok);
-            load4(xn, xp + 2 * H + ub, vec_x, n_ok);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) load4(xg[g], xp + g * H + ub, vec_x, n_ok);
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             PROF(1);
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
@@ -317,9 +320,9 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             PROFP(1);
         }
 
-        f32x4 acc[3];
+        f32x4 acc[NG];
 #pragma unroll
-        for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 cur[CHF], nxt[CHF];
 #pragma unroll
         for (int i = 0; i < CHF; ++i) cur[i] = ld_sc1(rin, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             }
 #pragma unroll
             for (int i = 0; i < CHF; ++i)
-                if (s0 + i < s_n) mfma_chunk<3>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
+                if (s0 + i < s_n) mfma_chunk<NG>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
 #pragma unroll
             for (int i = 0; i < CHF; ++i) cur[i] = nxt[i];
         }
@@ -340,7 +343,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 #endif
             PROFP(2);
 #pragma unroll
-            for (int g = 0; g < 3; ++g) parts[((slot0 + kp - 1) * 3 + g) * 64 + lane] = acc[g];
+            for (int g = 0; g < NG; ++g) parts[((slot0 + kp - 1) * NG + g) * 64 + lane] = acc[g];
             lds_signal(done, (unsigned)step + 1u);
             PROFP(3);
             continue;
@@ -355,19 +358,34 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             if (p == 1) PROF(7);
 #endif
 #pragma unroll
-            for (int g = 0; g < 3; ++g) acc[g] += parts[((slot0 + p - 1) * 3 + g) * 64 + lane];
+            for (int g = 0; g < NG; ++g) acc[g] += parts[((slot0 + p - 1) * NG + g) * 64 + lane];
         }
         PROF(3);
         // fused gate math: lane holds units ub..ub+3 of batch row b (pad units keep writing zeros)
         const bool live = row_ok && t < len;
-        float r[4], z[4], n[4], hn[4], hnew[4], outv[4];
+        // GRU: r, z, n, W_hn h + b_hn.  LSTM: i, f, g, o; v4 = tanh c_t
+        float v0[4], v1[4], v2[4], v3[4], v4[4], hnew[4], cnew[4], outv[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            r[c] = sigm(xr[c] + acc[0][c] + bh[0][c]);
-            z[c] = sigm(xz[c] + acc[1][c] + bh[1][c]);
-            hn[c] = acc[2][c] + bh[2][c];
-            n[c] = tanh_fast(xn[c] + r[c] * hn[c]);
-            const float hv = (1.f - z[c]) * n[c] + z[c] * hcur[c];
+            float hv;
+            if constexpr (LSTM) {
+                v0[c] = sigm(xg[0][c] + acc[0][c] + bh[0][c]);
+                v1[c] = sigm(xg[1][c] + acc[1][c] + bh[1][c]);
+                v2[c] = tanh_fast(xg[2][c] + acc[2][c] + bh[2][c]);
+                v3[c] = sigm(xg[3][c] + acc[3][c] + bh[3][c]);
+                const float cv = v1[c] * ccur[c] + v0[c] * v2[c];
+                v4[c] = tanh_fast(cv);
+                hv = v3[c] * v4[c];
+                cnew[c] = (c < n_ok && row_ok) ? (live ? cv : ccur[c]) : 0.f;
+            } else {
+                v0[c] = sigm(xg[0][c] + acc[0][c] + bh[0][c]);
+                v1[c] = sigm(xg[1][c] + acc[1][c] + bh[1][c]);
+                v3[c] = acc[2][c] + bh[2][c];
+                v2[c] = tanh_fast(xg[2][c] + v0[c] * v3[c]);
+                hv = (1.f - v1[c]) * v2[c] + v1[c] * hcur[c];
+                v4[c] = 0.f;
+                cnew[c] = 0.f;
+            }
             hnew[c] = (c < n_ok && row_ok) ? (live ? hv : hcur[c]) : 0.f;
             outv[c] = live ? hv : 0.f;
         }
@@ -385,28 +403,38 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         if (row_ok) {
             store4(in.out + bt * in.ldo + ub, outv, vec_h && (in.ldo % 4) == 0, n_ok);
             if (in.gates) {
-                float* gs = in.gates + bt * 5 * H + ub;
-                store4(gs, r, vec_h, n_ok);
-                store4(gs + H, z, vec_h, n_ok);
-                store4(gs + 2 * H, n, vec_h, n_ok);
-                store4(gs + 3 * H, hn, vec_h, n_ok);
-                store4(gs + 4 * H, hcur, vec_h, n_ok);
+                float* gs = in.gates + bt * (LSTM ? 7 : 5) * H + ub;
+                store4(gs, v0, vec_h, n_ok);
+                store4(gs + H, v1, vec_h, n_ok);
+                store4(gs + 2 * H, v2, vec_h, n_ok);
+                store4(gs + 3 * H, v3, vec_h, n_ok);
+                if constexpr (LSTM) {
+                    store4(gs + 4 * H, ccur, vec_h, n_ok);
+                    store4(gs + 5 * H, hcur, vec_h, n_ok);
+                    store4(gs + 6 * H, v4, vec_h, n_ok);
+                } else {
+                    store4(gs + 4 * H, hcur, vec_h, n_ok);
+                }
             }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) hcur[c] = hnew[c];
+        for (int c = 0; c < 4; ++c) { hcur[c] = hnew[c]; ccur[c] = cnew[c]; }
     }
     if (lead && row_ok && n_ok > 0 && in.h_last) store4(in.h_last + (size_t)b * H + ub, hcur, vec_h, n_ok);
+    if (LSTM && lead && row_ok && n_ok > 0 && in.c_last) store4(in.c_last + (size_t)b * H + ub, ccur, vec_h, n_ok);
 }
 
 // ------------------------------------------------------------------------------------------
 // WV waves per workgroup: 4 (64 batch rows) or 8 (128 rows: half the workgroups per recurrence, two waves per
 // SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
-template <int WV>
+// LSTM = true: four gate-gradient blocks per slice (d i, d f, d g, d o: the same for the input and the recurrent
+// product), d c carried in registers beside d h
+template <int WV, bool LSTM>
 __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     constexpr int NTHR = 64 * WV;
     constexpr int CB = WV > 8 ? 5 : CHB;
-    // chunk q = 3*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
+    constexpr int NG = LSTM ? 4 : 3;
+    // chunk q = NG*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
     int ii = 0;
     while (ii + 1 < args.n_inst && (int)blockIdx.x >= args.inst[ii + 1].wg_begin) ++ii;
@@ -414,7 +442,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const dssvae_gru_bwd_inst& in = d.in;
     const int local = blockIdx.x - d.wg_begin;
     const int bblock = local / d.n_slices, slice = local % d.n_slices;
-    const int H = in.H, T = in.T, B = in.B, K = 3 * H, NS = d.n_slices, NQ = 3 * NS;
+    const int H = in.H, T = in.T, B = in.B, K = NG * H, NS = d.n_slices, NQ = NG * NS;
     const int BB = d.rows, WVI = BB >> 4, KS = WV / WVI, BLK = BB * UU;
     const int Tt = in.T_total > 0 ? in.T_total : T;
     const int u0 = slice * UU;
@@ -436,15 +464,16 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
         const int q = idx >> 8, rem = idx & 255;
         const int kk = rem >> 4, i = rem & 15;  // i fastest: 16 consecutive floats of a W_hh row
-        const int p = q / 3, g = q - 3 * p;
+        const int p = q / NG, g = q - NG * p;
         const int cu = 16 * p + kk, u = u0 + i;
         const float w = (cu < H && u < H) ? in.whh[(size_t)(g * H + cu) * H + u] : 0.f;
         Ws[q * 256 + (kk & 3) * 64 + (kk >> 2) * 16 + i] = w;
     }
     if (KS > 1 && threadIdx.x < SYNC_WORDS) sync[threadIdx.x] = 0u;
     const int len = (in.lengths && row_ok) ? in.lengths[b] : Tt;
-    float dh[4] = {0.f, 0.f, 0.f, 0.f};
+    float dh[4] = {0.f, 0.f, 0.f, 0.f}, dc[4] = {0.f, 0.f, 0.f, 0.f};
     if (lead && row_ok && in.dh_last) load4(dh, in.dh_last + (size_t)b * H + ub, vec_h, n_ok);
+    if (LSTM && lead && row_ok && in.dc_last) load4(dc, in.dc_last + (size_t)b * H + ub, vec_h, n_ok);
 
     const unsigned half_bytes = (unsigned)NQ * BLK * 4u;
     float* gx0 = d.gx + (size_t)bblock * NQ * BLK;
@@ -455,7 +484,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(gx0 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u),
                                  rs1 = make_rsrc(gx1 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u);
     const int voff = ((rg * 16 + j) * UU + 4 * kq) * 4;
-    const int own = slice * 3 * BLK * 4;
+    const int own = slice * NG * BLK * 4;
     lds_word* go = sync + rg;
     lds_word* done = sync + 32 + wave;
     __syncthreads();
@@ -472,50 +501,78 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         float dhz[4] = {0.f, 0.f, 0.f, 0.f};
         if (lead) {
             const __amdgpu_buffer_rsrc_t wcur = (step & 1) ? ws1 : ws0;
-            float dgr[4] = {0.f, 0.f, 0.f, 0.f}, dgz[4] = {0.f, 0.f, 0.f, 0.f}, dgn[4] = {0.f, 0.f, 0.f, 0.f},
-                  dgm[4] = {0.f, 0.f, 0.f, 0.f};
+            // GRU: d r, d z, d n (input side), d n * r (recurrent side).  LSTM: d i, d f, d g, d o.
+            float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f},
+                  g3[4] = {0.f, 0.f, 0.f, 0.f};
             const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
             if (row_ok && n_ok > 0) {
                 const bool live = t < len;
                 if (live) {
                     float go_[4] = {0.f, 0.f, 0.f, 0.f};
                     if (in.dout) load4(go_, in.dout + bt * in.ldd + ub, vec_h && (in.ldd % 4) == 0, n_ok);
-                    const float* gs = in.gates + bt * 5 * H + ub;
-                    float r[4], z[4], n[4], hn[4], hp[4];
-                    load4(r, gs, vec_h, n_ok);
-                    load4(z, gs + H, vec_h, n_ok);
-                    load4(n, gs + 2 * H, vec_h, n_ok);
-                    load4(hn, gs + 3 * H, vec_h, n_ok);
-                    load4(hp, gs + 4 * H, vec_h, n_ok);
+                    const float* gs = in.gates + bt * (LSTM ? 7 : 5) * H + ub;
+                    float s0[4], s1[4], s2[4], s3[4], s4[4];
+                    load4(s0, gs, vec_h, n_ok);
+                    load4(s1, gs + H, vec_h, n_ok);
+                    load4(s2, gs + 2 * H, vec_h, n_ok);
+                    load4(s3, gs + 3 * H, vec_h, n_ok);
+                    if constexpr (LSTM) {
+                        float tc[4];
+                        load4(s4, gs + 4 * H, vec_h, n_ok);   // c_{t-1}
+                        load4(tc, gs + 6 * H, vec_h, n_ok);   // tanh c_t
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const float g = dh[c] + go_[c];
-                        const float dn = g * (1.f - z[c]) * (1.f - n[c] * n[c]);
-                        const bool ok = c < n_ok;
-                        dgn[c] = ok ? dn : 0.f;
-                        dgz[c] = ok ? g * (hp[c] - n[c]) * z[c] * (1.f - z[c]) : 0.f;
-                        dgr[c] = ok ? dn * hn[c] * r[c] * (1.f - r[c]) : 0.f;
-                        dgm[c] = ok ? dn * r[c] : 0.f;
-                        dhz[c] = g * z[c];
+                        for (int c = 0; c < 4; ++c) {
+                            const bool ok = c < n_ok;
+                            const float g = dh[c] + go_[c];
+                            const float dct = dc[c] + g * s3[c] * (1.f - tc[c] * tc[c]);
+                            g0[c] = ok ? dct * s2[c] * s0[c] * (1.f - s0[c]) : 0.f;
+                            g1[c] = ok ? dct * s4[c] * s1[c] * (1.f - s1[c]) : 0.f;
+                            g2[c] = ok ? dct * s0[c] * (1.f - s2[c] * s2[c]) : 0.f;
+                            g3[c] = ok ? g * tc[c] * s3[c] * (1.f - s3[c]) : 0.f;
+                            dc[c] = ok ? dct * s1[c] : 0.f;
+                            dhz[c] = 0.f;
+                        }
+                    } else {
+                        load4(s4, gs + 4 * H, vec_h, n_ok);   // h_{t-1}
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const float g = dh[c] + go_[c];
+                            const float dn = g * (1.f - s1[c]) * (1.f - s2[c] * s2[c]);
+                            const bool ok = c < n_ok;
+                            g2[c] = ok ? dn : 0.f;
+                            g1[c] = ok ? g * (s4[c] - s2[c]) * s1[c] * (1.f - s1[c]) : 0.f;
+                            g0[c] = ok ? dn * s3[c] * s0[c] * (1.f - s0[c]) : 0.f;
+                            g3[c] = ok ? dn * s0[c] : 0.f;
+                            dhz[c] = g * s1[c];
+                        }
                     }
                 } else {
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dhz[c] = dh[c];
+                    for (int c = 0; c < 4; ++c) dhz[c] = dh[c];   // (LSTM: d c passes through unchanged)
                 }
             }
-            // this slice's three gate blocks (pad units / pad rows publish zeros); hand over first, the
-            // dgx / dgh history stores then overlap the wait
+            // this slice's gate blocks (pad units / pad rows publish zeros); hand over first, the history stores
+            // then overlap the wait
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { sb_r[c] += dgr[c]; sb_z[c] += dgz[c]; sb_n[c] += dgn[c]; sb_m[c] += dgm[c]; }
-            st_sc1((f32x4){dgr[0], dgr[1], dgr[2], dgr[3]}, wcur, voff, own);
-            st_sc1((f32x4){dgz[0], dgz[1], dgz[2], dgz[3]}, wcur, voff, own + BLK * 4);
-            st_sc1((f32x4){dgm[0], dgm[1], dgm[2], dgm[3]}, wcur, voff, own + 2 * BLK * 4);
+            for (int c = 0; c < 4; ++c) { sb_r[c] += g0[c]; sb_z[c] += g1[c]; sb_n[c] += g2[c]; sb_m[c] += g3[c]; }
+            st_sc1((f32x4){g0[0], g0[1], g0[2], g0[3]}, wcur, voff, own);
+            st_sc1((f32x4){g1[0], g1[1], g1[2], g1[3]}, wcur, voff, own + BLK * 4);
+            if constexpr (LSTM) {
+                st_sc1((f32x4){g2[0], g2[1], g2[2], g2[3]}, wcur, voff, own + 2 * BLK * 4);
+                st_sc1((f32x4){g3[0], g3[1], g3[2], g3[3]}, wcur, voff, own + 3 * BLK * 4);
+            } else {
+                st_sc1((f32x4){g3[0], g3[1], g3[2], g3[3]}, wcur, voff, own + 2 * BLK * 4);
+            }
             publish(cnt);
             if (row_ok && n_ok > 0) {
                 float* ox = in.dgx + bt * K + ub;
-                float* oh = in.dgh + bt * K + ub;
-                store4(ox, dgr, vec_h, n_ok); store4(ox + H, dgz, vec_h, n_ok); store4(ox + 2 * H, dgn, vec_h, n_ok);
-                store4(oh, dgr, vec_h, n_ok); store4(oh + H, dgz, vec_h, n_ok); store4(oh + 2 * H, dgm, vec_h, n_ok);
+                store4(ox, g0, vec_h, n_ok); store4(ox + H, g1, vec_h, n_ok); store4(ox + 2 * H, g2, vec_h, n_ok);
+                if constexpr (LSTM) {
+                    store4(ox + 3 * H, g3, vec_h, n_ok);
+                } else {
+                    float* oh = in.dgh + bt * K + ub;
+                    store4(oh, g0, vec_h, n_ok); store4(oh + H, g1, vec_h, n_ok); store4(oh + 2 * H, g3, vec_h, n_ok);
+                }
             }
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
@@ -561,6 +618,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     }
     if (!lead) return;
     if (row_ok && n_ok > 0 && in.dh0) store4(in.dh0 + (size_t)b * H + ub, dh, vec_h, n_ok);
+    if (LSTM && row_ok && n_ok > 0 && in.dc0) store4(in.dc0 + (size_t)b * H + ub, dc, vec_h, n_ok);
     if (in.dbias_x || in.dbias_h) {
         // sum over the 16 batch rows of the wave (lanes with the same unit quad), then one atomic per unit
 #pragma unroll
@@ -579,10 +637,15 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                     if (in.dbias_x) {
                         atomicAdd(in.dbias_x + u, sb_r[c]); atomicAdd(in.dbias_x + H + u, sb_z[c]);
                         atomicAdd(in.dbias_x + 2 * H + u, sb_n[c]);
+                        if (LSTM) atomicAdd(in.dbias_x + 3 * H + u, sb_m[c]);
                     }
                     if (in.dbias_h) {
                         atomicAdd(in.dbias_h + u, sb_r[c]); atomicAdd(in.dbias_h + H + u, sb_z[c]);
-                        atomicAdd(in.dbias_h + 2 * H + u, sb_m[c]);
+                        if (LSTM) {  // the gate pre-activations are sums of both products: the same gradient
+                            atomicAdd(in.dbias_h + 2 * H + u, sb_n[c]); atomicAdd(in.dbias_h + 3 * H + u, sb_m[c]);
+                        } else {
+                            atomicAdd(in.dbias_h + 2 * H + u, sb_m[c]);
+                        }
                     }
                 }
         }
@@ -596,7 +659,8 @@ struct Layout {
 
 inline int round16(int x) { return (x + 15) & ~15; }
 
-// exchange buffers are sized for the backward pass (3 gate blocks per slice); forward uses a third.  The sizes
+// exchange buffers are sized for the backward pass of either cell (4 gate blocks per slice: the LSTM's; the GRU's
+// backward uses 3, forward 1).  The sizes
 // hold for every cell height (16 .. 128 rows): counters are per 16-row group, buffers per 128-row-padded batch.
 Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     Layout L;
@@ -609,7 +673,7 @@ Layout plan(int n_inst, const int32_t* B, const int32_t* H) {
     L.header_bytes = off;
     for (int i = 0; i < n_inst; ++i) {
         L.buf_off[i] = off;
-        off += (size_t)2 * ((B[i] + 127) / 128) * 128 * 3 * round16(H[i]) * sizeof(float);  // either block size
+        off += (size_t)2 * ((B[i] + 127) / 128) * 128 * 4 * round16(H[i]) * sizeof(float);  // either block size
         off = (off + 255) & ~(size_t)255;
     }
     L.total_bytes = off;
@@ -626,45 +690,56 @@ int cu_count() {
     return cus;
 }
 
-const void* fwd_kernel(int wv) {
-    switch (wv) {
-        case 1: return reinterpret_cast<const void*>(gru_fwd_kernel<1>);
-        case 2: return reinterpret_cast<const void*>(gru_fwd_kernel<2>);
-        case 4: return reinterpret_cast<const void*>(gru_fwd_kernel<4>);
-        case 8: return reinterpret_cast<const void*>(gru_fwd_kernel<8>);
-        default: return reinterpret_cast<const void*>(gru_fwd_kernel<16>);
+const void* fwd_kernel(int wv, bool lstm) {
+#define PICK(L)                                                                              \
+    switch (wv) {                                                                            \
+        case 1: return reinterpret_cast<const void*>(gru_fwd_kernel<1, L>);                  \
+        case 2: return reinterpret_cast<const void*>(gru_fwd_kernel<2, L>);                  \
+        case 4: return reinterpret_cast<const void*>(gru_fwd_kernel<4, L>);                  \
+        case 8: return reinterpret_cast<const void*>(gru_fwd_kernel<8, L>);                  \
+        default: return reinterpret_cast<const void*>(gru_fwd_kernel<16, L>);                \
     }
+    if (lstm) { PICK(true) }
+    PICK(false)
+#undef PICK
 }
-const void* bwd_kernel(int wv) {
-    switch (wv) {
-        case 1: return reinterpret_cast<const void*>(gru_bwd_kernel<1>);
-        case 2: return reinterpret_cast<const void*>(gru_bwd_kernel<2>);
-        case 4: return reinterpret_cast<const void*>(gru_bwd_kernel<4>);
-        case 8: return reinterpret_cast<const void*>(gru_bwd_kernel<8>);
-        default: return reinterpret_cast<const void*>(gru_bwd_kernel<16>);
+const void* bwd_kernel(int wv, bool lstm) {
+#define PICK(L)                                                                              \
+    switch (wv) {                                                                            \
+        case 1: return reinterpret_cast<const void*>(gru_bwd_kernel<1, L>);                  \
+        case 2: return reinterpret_cast<const void*>(gru_bwd_kernel<2, L>);                  \
+        case 4: return reinterpret_cast<const void*>(gru_bwd_kernel<4, L>);                  \
+        case 8: return reinterpret_cast<const void*>(gru_bwd_kernel<8, L>);                  \
+        default: return reinterpret_cast<const void*>(gru_bwd_kernel<16, L>);                \
     }
+    if (lstm) { PICK(true) }
+    PICK(false)
+#undef PICK
 }
 
-inline int slice_bytes_for(int H_max) { return 3 * (round16(H_max) / UU) * 256 * (int)sizeof(float); }
+inline int slice_bytes_for(int H_max, bool lstm) {
+    return (lstm ? 4 : 3) * (round16(H_max) / UU) * 256 * (int)sizeof(float);
+}
 // LDS of a launch: the resident W_hh slice; with the K split (some instance has more waves than row groups) the
 // waves' partial sums and the sync words behind it
-inline int lds_bytes_for(bool backward, int H_max, int wv, int min_rows) {
+inline int lds_bytes_for(bool backward, bool lstm, int H_max, int wv, int min_rows) {
     const int parts = wv - min_rows / 16;  // non-lead waves of the instance with the fewest row groups
-    return slice_bytes_for(H_max) + (parts > 0 ? parts * (backward ? 1 : 3) * PART_BYTES + SYNC_WORDS * 4 : 0);
+    return slice_bytes_for(H_max, lstm) +
+           (parts > 0 ? parts * (backward ? 1 : lstm ? 4 : 3) * PART_BYTES + SYNC_WORDS * 4 : 0);
 }
 
 // How many workgroups of a persistent launch the chip holds AT ONCE: the runtime's occupancy answer for this
 // kernel, block size and LDS size, times the CU count.  Every workgroup of a launch must be resident (the step
 // hand-off spins on peers), so this is the bound on the grid -- not the CU count: an H = 300 slice is 57 KB of
 // the CU's 160 KB of LDS, two such 4-wave workgroups share a CU.  0 = it does not fit at all.
-int resident_workgroups(bool backward, int wv, int lds_bytes) {
+int resident_workgroups(bool backward, bool lstm, int wv, int lds_bytes) {
     if (lds_bytes > LDS_MAX || lds_bytes <= 0) return 0;
     // the answer depends on (kernel, block size, LDS size) only: asked once (sizes are multiples of 256 B)
-    static int cache[2][5][LDS_MAX / 256 + 1];  // 0 = not asked yet, -1 = asked: none
+    static int cache[4][5][LDS_MAX / 256 + 1];  // 0 = not asked yet, -1 = asked: none
     const int wi = wv == 1 ? 0 : wv == 2 ? 1 : wv == 4 ? 2 : wv == 8 ? 3 : 4;
-    int& c = cache[backward ? 1 : 0][wi][lds_bytes / 256];
+    int& c = cache[(backward ? 1 : 0) + (lstm ? 2 : 0)][wi][lds_bytes / 256];
     if (c == 0) {
-        const void* k = backward ? bwd_kernel(wv) : fwd_kernel(wv);
+        const void* k = backward ? bwd_kernel(wv, lstm) : fwd_kernel(wv, lstm);
         int per_cu = 0;
         // the attribute is per kernel, not per launch: raise it to the CU's LDS once, whatever this launch needs
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX) != hipSuccess ||
@@ -683,8 +758,8 @@ int resident_workgroups(bool backward, int wv, int lds_bytes) {
 //   then the layouts without K split: 64 rows / 4 waves (several workgroups per CU), 128 rows / 8 waves.
 // DSSVAE_GRU_WAVES=8 forces 128 rows / 8 waves, DSSVAE_GRU_KSPLIT=0 skips the K-split layouts (tests, A/B).
 // -> waves per workgroup (1 .. 16), 0 = not resident any way, -1 = bad rows value
-int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want, int* rows_out,
-              int* lds_out) {
+int pick_rows(bool backward, bool lstm, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want,
+              int* rows_out, int* lds_out) {
     int max_h = 0;
     bool any_auto = false;
     for (int i = 0; i < n_inst; ++i) {
@@ -708,13 +783,13 @@ int pick_rows(bool backward, int n_inst, const int32_t* B, const int32_t* H, con
             if (rows_out[i] < min_rows) min_rows = rows_out[i];
         }
         const int wv = cand[c].wv16 ? 16 : max_rows / 16;
-        const int lds = lds_bytes_for(backward, max_h, wv, min_rows);
-        if (slice_bytes_for(max_h) > LDS_BUDGET) return 0;
-        const int res = resident_workgroups(backward, wv, lds);
+        const int lds = lds_bytes_for(backward, lstm, max_h, wv, min_rows);
+        if (slice_bytes_for(max_h, lstm) > LDS_BUDGET) return 0;
+        const int res = resident_workgroups(backward, lstm, wv, lds);
         static const bool verbose = getenv("DSSVAE_GRU_VERBOSE") != nullptr;
         if (verbose)
-            fprintf(stderr, "[dssvae gru %s] layout %d: rows %d..%d, %d waves, LDS %d B, grid %d, resident %d\n",
-                    backward ? "bwd" : "fwd", c, min_rows, max_rows, wv, lds, wg, res);
+            fprintf(stderr, "[dssvae %s %s] layout %d: rows %d..%d, %d waves, LDS %d B, grid %d, resident %d\n",
+                    lstm ? "lstm" : "gru", backward ? "bwd" : "fwd", c, min_rows, max_rows, wv, lds, wg, res);
         if (wg <= res) {
             *lds_out = lds;
             return wv;
@@ -752,7 +827,7 @@ extern "C" int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host,
 extern "C" int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host) {
     if (!n_host || H_max <= 0 || (rows_max != 16 && rows_max != 32 && rows_max != 64 && rows_max != 128))
         return DSSVAE_EINVAL;
-    *n_host = resident_workgroups(backward != 0, rows_max / 16, slice_bytes_for(H_max));
+    *n_host = resident_workgroups(backward != 0, false, rows_max / 16, slice_bytes_for(H_max, false));
     return DSSVAE_OK;
 }
 
@@ -760,9 +835,13 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
                               void* stream) {
     if (!inst || n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !workspace) return DSSVAE_EINVAL;
     int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST], want[DSSVAE_GRU_MAX_INST];
+    const bool lstm = inst[0].cell == DSSVAE_CELL_LSTM;
     for (int i = 0; i < n_inst; ++i) {
         const dssvae_gru_fwd_inst& x = inst[i];
-        if (!x.xproj || !x.whh || !x.bhh || !x.out || x.B <= 0 || x.T <= 0 || x.H <= 0 || x.ldx < 3 * x.H ||
+        if ((x.cell != DSSVAE_CELL_GRU && x.cell != DSSVAE_CELL_LSTM) || (x.cell == DSSVAE_CELL_LSTM) != lstm)
+            return DSSVAE_EINVAL;  // one cell type per launch
+        if (!x.xproj || !x.whh || !x.bhh || !x.out || x.B <= 0 || x.T <= 0 || x.H <= 0 ||
+            x.ldx < (lstm ? 4 : 3) * x.H ||
             x.ldo < x.H || x.t0 < 0 || (x.T_total > 0 && x.t0 + x.T > x.T_total) || (x.T_total <= 0 && x.t0 != 0))
             return DSSVAE_EINVAL;
         Bs[i] = x.B; Hs[i] = x.H; want[i] = x.rows;
@@ -775,7 +854,7 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
     args.sticky = sticky_word();
     int rows[DSSVAE_GRU_MAX_INST];
     int lds_bytes = 0;
-    const int wv = pick_rows(false, n_inst, Bs, Hs, want, rows, &lds_bytes);
+    const int wv = pick_rows(false, lstm, n_inst, Bs, Hs, want, rows, &lds_bytes);
     if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
     int wg = 0, max_h = 0;
@@ -796,7 +875,7 @@ extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void*
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
     void* kargs[] = {&args};
-    const hipError_t le = hipLaunchKernel(fwd_kernel(wv), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
+    const hipError_t le = hipLaunchKernel(fwd_kernel(wv, lstm), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
     if (le != hipSuccess) return (int)le;
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
@@ -806,9 +885,13 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
                               void* stream) {
     if (!inst || n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !workspace) return DSSVAE_EINVAL;
     int32_t Bs[DSSVAE_GRU_MAX_INST], Hs[DSSVAE_GRU_MAX_INST], want[DSSVAE_GRU_MAX_INST];
+    const bool lstm = inst[0].cell == DSSVAE_CELL_LSTM;
     for (int i = 0; i < n_inst; ++i) {
         const dssvae_gru_bwd_inst& x = inst[i];
-        if (!x.whh || !x.gates || !x.dgx || !x.dgh || x.B <= 0 || x.T <= 0 || x.H <= 0 || (x.dout && x.ldd < x.H) ||
+        if ((x.cell != DSSVAE_CELL_GRU && x.cell != DSSVAE_CELL_LSTM) || (x.cell == DSSVAE_CELL_LSTM) != lstm)
+            return DSSVAE_EINVAL;
+        if (!x.whh || !x.gates || !x.dgx || (!lstm && !x.dgh) || x.B <= 0 || x.T <= 0 || x.H <= 0 ||
+            (x.dout && x.ldd < x.H) ||
             x.t0 < 0 || (x.T_total > 0 && x.t0 + x.T > x.T_total) || (x.T_total <= 0 && x.t0 != 0))
             return DSSVAE_EINVAL;
         Bs[i] = x.B; Hs[i] = x.H; want[i] = x.rows;
@@ -821,7 +904,7 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     args.sticky = sticky_word();
     int rows[DSSVAE_GRU_MAX_INST];
     int lds_bytes = 0;
-    const int wv = pick_rows(true, n_inst, Bs, Hs, want, rows, &lds_bytes);
+    const int wv = pick_rows(true, lstm, n_inst, Bs, Hs, want, rows, &lds_bytes);
     if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
     int wg = 0, max_h = 0;
@@ -842,7 +925,7 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
                                 (int)(L.header_bytes / 4), s);
     if (e != DSSVAE_OK) return e;
     void* kargs[] = {&args};
-    const hipError_t le = hipLaunchKernel(bwd_kernel(wv), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
+    const hipError_t le = hipLaunchKernel(bwd_kernel(wv, lstm), dim3(wg), dim3(64 * wv), kargs, lds_bytes, s);
     if (le != hipSuccess) return (int)le;
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;

@@ -25,7 +25,7 @@ class GruFwdInst(C.Structure):
                 ("h0", C.c_void_p), ("lengths", C.c_void_p), ("out", C.c_void_p), ("ldo", C.c_int64),
                 ("h_last", C.c_void_p), ("gates", C.c_void_p), ("B", C.c_int32), ("T", C.c_int32),
                 ("H", C.c_int32), ("reverse", C.c_int32), ("t0", C.c_int32), ("T_total", C.c_int32),
-                ("rows", C.c_int32), ("reserved", C.c_int32)]
+                ("rows", C.c_int32), ("cell", C.c_int32), ("c0", C.c_void_p), ("c_last", C.c_void_p)]
 
 
 class GruBwdInst(C.Structure):
@@ -34,7 +34,10 @@ class GruBwdInst(C.Structure):
                 ("dh_last", C.c_void_p), ("dgx", C.c_void_p), ("dgh", C.c_void_p), ("dh0", C.c_void_p),
                 ("B", C.c_int32), ("T", C.c_int32), ("H", C.c_int32), ("reverse", C.c_int32),
                 ("dbias_x", C.c_void_p), ("dbias_h", C.c_void_p), ("t0", C.c_int32), ("T_total", C.c_int32),
-                ("rows", C.c_int32), ("reserved", C.c_int32)]
+                ("rows", C.c_int32), ("cell", C.c_int32), ("dc_last", C.c_void_p), ("dc0", C.c_void_p)]
+
+
+CELL_GRU, CELL_LSTM = 0, 1
 
 
 GEMM_MAX_GROUP = 8

@@ -1197,9 +1197,17 @@ def gru_layer(insts, lengths=None, save=None, check=False):
 
 
 # ----------------------------------------------------------------------------------------------
-# LSTM (rnn_cell = "lstm" of the reference's RNNBase): stepwise -- per timestep the recurrent product on the MFMA
-# GEMM + one fused cell kernel (dssvae_lstm_step_*), same saved-history idea as the stepwise GRU
+# LSTM (rnn_cell = "lstm" of the reference's RNNBase).  A recurrence whose W_hh slice (4 gates x 16 units x H) fits the
+# persistent kernel's LDS budget runs through the same persistent kernels as the GRU (cell = LSTM: csrc/gru.hip);
+# larger ones stepwise -- per timestep the recurrent product on the MFMA GEMM + one fused cell kernel
+# (dssvae_lstm_step_*).  Both write the same saved history, so either backward reads either forward's.
 # ----------------------------------------------------------------------------------------------
+def _lstm_fits_persistent(B, H):
+    if FORCE_STEPWISE_GRU:
+        return False
+    return _cells(B, H) <= n_cus() and 4 * ((H + 15) // 16) * 1024 <= GRU_LDS_BUDGET
+
+
 class _LstmFn(Function):
     """(xproj [B,T,4H] incl. b_ih, whh [4H,H], bhh [4H], h0 [B,H], c0 [B,H], bih [4H] or empty -- gradient routing
     only) -> (out [B,T,H], h_T, c_T); gate order i, f, g, o; lengths: packed-sequence semantics; reverse: walks
@@ -1219,10 +1227,23 @@ class _LstmFn(Function):
         ldx = _xproj_ld(x)
         out = torch.empty(B, T, H, device=dev, dtype=torch.float32)
         gates = torch.empty(B, T, 7 * H, device=dev, dtype=torch.float32) if save else None
-        gh = torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
         h, c = h0.contiguous(), c0.contiguous()
         lp = None if lengths is None else lengths.data_ptr()
-        for step in range(T):
+        ctx.persistent = _lstm_fits_persistent(B, H)
+        if ctx.persistent:
+            hl, cl = torch.empty_like(h), torch.empty_like(c)
+            arr = (L.GruFwdInst * 1)()
+            arr[0] = L.GruFwdInst(x.data_ptr(), ldx, whh.data_ptr(), bhh.data_ptr(), h.data_ptr(), lp, out.data_ptr(), H,
+                                  hl.data_ptr(), None if gates is None else gates.data_ptr(), B, T, H, int(bool(reverse)),
+                                  0, T, 0, L.CELL_LSTM, c.data_ptr(), cl.data_ptr())
+            wsb, nbytes = _workspace([B], [H], dev)
+            _note_persistent_error(wsb)
+            with _PersistentTurn(dev), _Span("lstm_fwd_kernel", 8.0 * B * T * H * H,
+                                             4.0 * B * T * H * (11 if save else 5), T, detail="B%dT%dH%d" % (B, T, H)):
+                L.check(lib.dssvae_gru_fwd(arr, 1, L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_fwd (lstm)")
+            h, c = hl, cl
+        gh = None if ctx.persistent else torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
+        for step in range(0 if ctx.persistent else T):
             t = T - 1 - step if reverse else step
             mm_nt(h, whh, out=gh)
             hn, cn = torch.empty_like(h), torch.empty_like(c)
@@ -1250,7 +1271,26 @@ class _LstmFn(Function):
         dh = None if dhT is None else dhT.contiguous()
         dc = None if dcT is None else dcT.contiguous()
         lp = None if ctx.lengths is None else ctx.lengths.data_ptr()
-        for step in range(T):
+        need = ctx.needs_input_grad
+        db = None
+        if ctx.persistent:
+            dh0 = torch.empty(B, H, device=dev, dtype=torch.float32)
+            dc0 = torch.empty(B, H, device=dev, dtype=torch.float32)
+            if need[2] or need[5]:  # accumulated by the kernel (atomics): starts at zero
+                db = torch.zeros(4 * H, device=dev, dtype=torch.float32)
+            arr = (L.GruBwdInst * 1)()
+            arr[0] = L.GruBwdInst(whh.data_ptr(), None, lp, None, 0, gates.data_ptr(),
+                                  None if dout is None else dout.data_ptr(), 0 if dout is None else H,
+                                  None if dh is None else dh.data_ptr(), dg.data_ptr(), None, dh0.data_ptr(), B, T, H,
+                                  int(ctx.reverse), None if db is None else db.data_ptr(), None, 0, T, 0, L.CELL_LSTM,
+                                  None if dc is None else dc.data_ptr(), dc0.data_ptr())
+            wsb, nbytes = _workspace([B], [H], dev)
+            _note_persistent_error(wsb)
+            with _PersistentTurn(dev), _Span("lstm_bwd_kernel", 8.0 * B * T * H * H, 4.0 * B * T * H * 12, T,
+                                             detail="B%dT%dH%d" % (B, T, H)):
+                L.check(lib.dssvae_gru_bwd(arr, 1, L.ptr(wsb), nbytes, L.stream()), "dssvae_gru_bwd (lstm)")
+            dh, dc = dh0, dc0
+        for step in range(0 if ctx.persistent else T):
             fstep = T - 1 - step
             t = T - 1 - fstep if ctx.reverse else fstep
             dhz = torch.empty(B, H, device=dev, dtype=torch.float32)
@@ -1261,12 +1301,12 @@ class _LstmFn(Function):
                 L.ptr(dhz), L.ptr(dcp), L.stream()), "dssvae_lstm_step_bwd")
             mm_nn(dg[:, t, :], whh, out=dhz, beta=1.0)
             dh, dc = dhz, dcp
-        need = ctx.needs_input_grad
         W_ref, bhh_ref, bih_ref = ctx.refs
         rows = B * T
         dg2 = dg.view(rows, 4 * H)
         dW = mm_tn(dg2, gates.view(rows, 7 * H)[:, 5 * H:6 * H], out=_claim(W_ref, need[1])) if need[1] else None
-        db = colsum(dg2) if (need[2] or need[5]) else None
+        if db is None and (need[2] or need[5]):
+            db = colsum(dg2)
         return (dg if need[0] else None, dW, db if need[2] else None, dh if need[3] else None, dc if need[4] else None,
                 db if (need[5] and bih_ref.numel()) else None, None, None)
 

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 4 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches */
+#define DSSVAE_ABI_VERSION 4 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -210,8 +210,17 @@ int dssvae_reparam_kl_bwd(const float* mean, const float* logv, const float* eps
  *   h_last [B,H]     : final state;  gates [B,T,5H]: r,z,n,(W_hn h + b_hn),h_{t-1} saved for
  *                      backward (NULL in inference)
  * sync: caller-provided workspace of dssvae_gru_workspace_bytes(...) bytes, need not be zeroed.
+ *
+ * cell = DSSVAE_CELL_LSTM runs an LSTM recurrence (nn.LSTM behind RNNBase's rnn_cell = "lstm", networks/rnn_base.py:
+ * 32-36) through the same kernels and entry points (one cell type per launch): gate order i, f, g, o; xproj
+ * [B,T,4H], whh [4H,H], bhh [4H]; c0 / c_last [B,H] beside h0 / h_last; `gates` rows are the stepwise kernels' saved
+ * row [i | f | g | o | c_{t-1} | h_{t-1} | tanh c_t] (7H).  Backward: dgx [B,T,4H] is the gradient wrt the gate
+ * pre-activations (the same for the input and the recurrent product: dgh is not written and may be NULL; dbias_x and
+ * dbias_h, [4H] each, receive the same sums), dc_last / dc0 beside dh_last / dh0.
  * ------------------------------------------------------------------------------------------- */
 #define DSSVAE_GRU_MAX_INST 8
+#define DSSVAE_CELL_GRU 0
+#define DSSVAE_CELL_LSTM 1
 typedef struct {
     const float* xproj; int64_t ldx;
     const float* whh; const float* bhh; const float* h0;
@@ -227,7 +236,9 @@ typedef struct {
     int32_t t0, T_total;
     /* batch rows per workgroup ("cell" = rows x 16 hidden units): 16, 32, 64 or 128; 0 = the library chooses for
      * the launch (64 when the grid is resident that way, else 128) */
-    int32_t rows, reserved;
+    int32_t rows;
+    int32_t cell;                     /* DSSVAE_CELL_GRU (0) or DSSVAE_CELL_LSTM */
+    const float* c0; float* c_last;   /* LSTM only: cell state at the segment's ends ([B,H]; c0 NULL = zeros, c_last may be NULL) */
 } dssvae_gru_fwd_inst;
 
 typedef struct {
@@ -245,7 +256,9 @@ typedef struct {
     /* segment of the recurrence and cell height, as in dssvae_gru_fwd_inst: this launch walks forward steps
      * t0 + T - 1 down to t0; dh_last / dh0 are the gradients wrt the states at the segment's ends */
     int32_t t0, T_total;
-    int32_t rows, reserved;
+    int32_t rows;
+    int32_t cell;                          /* as in dssvae_gru_fwd_inst */
+    const float* dc_last; float* dc0;      /* LSTM only: gradients wrt the cell state at the segment's ends (may be NULL) */
 } dssvae_gru_bwd_inst;
 
 int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int32_t* H_host);
