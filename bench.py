@@ -177,23 +177,29 @@ def generate_bench(a, model, vocab, margs, rank, world, margs_dict=None):
         lib.dssvae_decode_profile(0)
         out["prior_sampling"] = {"sentences": len(res), "seconds": dt, "sentences_per_s": len(res) / dt}
         if launches.value:
-            # dominant kernel of the loop: [h ; e] W_out^T fused with the arg-max.  Algorithmic bytes per launch: W_out
-            # once (4 V (H + E)); the activations and partials are noise beside it.  MFMA work per launch: the decode
-            # batch padded to the kernel's 32-row groups.
+            # dominant kernel of the loop: [h ; e] W_out^T fused with the arg-max.  Measured bound (tools/gen_clock.py,
+            # development builds without the loads / without the MFMAs: 40 us of matrix work, 26 us of stream, 43 us
+            # together): the fp32 MFMA rate on the decode batch padded to the kernel's row groups.  Algorithmic flops
+            # per launch: the UNPADDED batch; algorithmic bytes: W_out once (4 V (H + E)), the activations and
+            # partials are noise beside it.
             dec = model.decoder
             H, E, V = dec.hidden_size, dec.input_size, dec.vocab_size
             avg_ms = tot_ms.value / launches.value
             nbytes = 4.0 * V * (H + E)
-            rows = (bs + 31) // 32 * 32
-            flops = 2.0 * rows * V * (H + E)
+            group = lib.dssvae_skinny_argmax_rows(bs, V)
+            rows = (bs + group - 1) // group * group
+            flops, flops_padded = 2.0 * bs * V * (H + E), 2.0 * rows * V * (H + E)
             gbs = nbytes / (avg_ms * 1e-3) / 1e9
-            tf = flops / (avg_ms * 1e-3) / 1e12
-            out["roofline"] = {"kernel": "skinny_kernel<ARGMAX>", "bound": "hbm", "achieved": gbs, "peak": PEAK_HBM_GBS,
-                               "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "traffic": None,
-                               "algorithmic_bytes_per_launch": nbytes, "avg_launch_us": 1e3 * avg_ms,
+            tf, tf_padded = flops / (avg_ms * 1e-3) / 1e12, flops_padded / (avg_ms * 1e-3) / 1e12
+            out["roofline"] = {"kernel": "skinny_argmax64_kernel" if group == 64 else "skinny_kernel<ARGMAX>",
+                               "bound": "mfma", "achieved": tf, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                               "frac": tf / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                               "algorithmic_flops_per_launch": flops, "avg_launch_us": 1e3 * avg_ms,
                                "launches": launches.value, "share_of_wall": tot_ms.value * 1e-3 / dt,
-                               "mfma": {"flops_per_launch_padded_rows": flops, "tflops": tf,
-                                        "frac": tf / PEAK_F32_MFMA_TFLOPS, "rows": rows}}
+                               "padded_rows": {"rows": rows, "flops_per_launch": flops_padded, "tflops": tf_padded,
+                                               "frac": tf_padded / PEAK_F32_MFMA_TFLOPS},
+                               "hbm": {"algorithmic_bytes_per_launch": nbytes, "achieved_GBps": gbs,
+                                       "frac": gbs / PEAK_HBM_GBS}}
         if a.model == "SyntaxVAE2":
             exs = synthetic.examples(bs, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len, fixed=False,
                                      seed=99 + rank)

@@ -1,4 +1,5 @@
-// Skinny projections for the generation loop (M = a decode batch of a few dozen rows):
+// Skinny projections for the generation loop (M = a decode batch of a few dozen rows; the arg-max over a large
+// vocabulary at 33+ rows has a kernel of its own further down, skinny_argmax64_kernel):
 //   C[M,N] = [X1 | X2] . W^T + bias            (GRU gate pre-activations of one step)
 //   argmax_n ([X1 | X2] . W^T + bias)[m, n]    (greedy token: decoder/rnn_decoder.py:70-73 + topk(1))
 // At M <= 128 the 128x128 LDS-tiled GEMM wastes most of its tile and runs a handful of workgroups;
@@ -8,6 +9,7 @@
 // of v_mfma_f32_16x16x4_f32 (exact fp32) with register double-buffered prefetch, and applies them to
 // both 16-row activation tiles.  Bound: HBM / Infinity-Cache bandwidth (2 flop per byte of W per tile).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -27,9 +29,8 @@ inline int padded_k(int K) { return ((K + 15) / 16) * 16 + 4; }
 // columns k..k+3 (zeros for padding).  Eight loads are in flight per thread before the first LDS store: with
 // one load per trip (load -> wait -> store) the fill is ~60 dependent L2 round trips and takes longer than
 // the weight stream it prepares.
-template <int THREADS, class F>
+template <int THREADS, class F, int U = 8>
 __device__ __forceinline__ void fill_image(float* Xs, int rows, int Kp, F fetch) {
-    constexpr int U = 8;
     const int kp4 = Kp >> 2, total = rows * kp4;
     for (int base = threadIdx.x; base < total; base += THREADS * U) {
         float4 v[U];
@@ -215,6 +216,180 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     }
 }
 
+
+// The arg-max for decode batches of 33 .. 64 rows per row chunk (generation at eval_bs 50): with 32-row workgroups
+// every element of W is streamed twice and feeds 8 MFMAs per KB -- at the full MFMA rate that is 8 TB/s into the
+// CUs, so the kernel sat at half the matrix rate.  Here a workgroup holds 64 activation rows (4 MFMA tiles) and
+// every wave owns ONE 16-column block of W for the whole kernel: 16 MFMAs per KB of W, W streamed once.  64 rows
+// x K = 900 do not fit LDS (231 KB), so K is cut into passes (2 at K = 900): the image of a pass's k range is
+// built in LDS, the waves stream that k range of their block, and the block's 4 accumulators stay in registers
+// across the passes.  The first weight chunk of a pass is in flight while the image is built.
+constexpr int SK64_ROWS = 64, SK64_TILES = 4;
+#ifdef SK_PROFILE
+// development build: shader-clock and 100 MHz wall-clock ticks of workgroup 0's wave 0 over the kernel -> the clock
+// the chip actually runs the generation loop at
+__device__ unsigned long long g_skclk[2];
+#endif
+
+#ifdef SK_NO_LOAD   // development: the matrix work alone (no weight stream)
+#define SK_LOADW(p) ((f32x4){(float)(uintptr_t)(p), 1.f, 2.f, 3.f})
+#else
+#define SK_LOADW(p) (*reinterpret_cast<const f32x4*>(p))
+#endif
+constexpr int SK64_GC = 8;  // k-groups per register chunk: 8 KB per wave, 128 KB per CU in flight
+
+// One register chunk of the stream: GC k-groups x (4 activation reads from LDS + 16 MFMAs).  FULL = every group of
+// the chunk is inside the pass: no branches at all, so the compiler counts the outstanding weight loads (the prefetch
+// of the next chunk stays in flight: s_waitcnt vmcnt(n > 0)) and moves the LDS reads ahead of the MFMAs that hide them.
+template <bool FULL>
+__device__ __forceinline__ void sk64_chunk(f32x4 (&acc)[SK64_TILES], const f32x4 (&cur)[SK64_GC], const float* xs, int Kp,
+                                           int goff, int n_valid) {
+#pragma unroll
+    for (int i = 0; i < SK64_GC; ++i) {
+        if (FULL || i < n_valid) {
+            f32x4 x[SK64_TILES];
+#pragma unroll
+            for (int t = 0; t < SK64_TILES; ++t)
+                x[t] = *reinterpret_cast<const f32x4*>(xs + t * 16 * Kp + 16 * (goff + i));
+#ifdef SK_NO_MFMA   // development: the stream alone (the loaded values are consumed by cheap adds)
+#pragma unroll
+            for (int t = 0; t < SK64_TILES; ++t) acc[t] += cur[i] * x[t];
+#else
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < SK64_TILES; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x[t][j], acc[t], 0, 0, 0);
+#endif
+        }
+    }
+}
+
+__global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
+    const float* __restrict__ X1, int64_t ld1, int K1, const float* __restrict__ X2, int64_t ld2, int K2,
+    const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp, int g_per_pass,
+    float* __restrict__ part_max, float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split,
+    int m_chunks) {
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [64][Kp]: the k range of the current pass
+    __shared__ float red_v[SK_WAVES][SK64_ROWS];
+    __shared__ int red_i[SK_WAVES][SK64_ROWS];
+    constexpr int GC = SK64_GC;
+    const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int bx = (seq / m_chunks) * 8 + xcd, by = seq % m_chunks;
+    if (bx >= n_split) return;
+    const int K = K1 + K2;
+    const int m0 = by * SK64_ROWS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#ifdef SK_PROFILE
+    const unsigned long long c0 = clock64(), w0 = wall_clock64();
+#endif
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int nG = (K + 15) >> 4;
+    const int NB = (N + 15) >> 4;
+    const int blk = bx * SK_WAVES + wave;
+    const bool active = blk < NB;
+    const int n = min(blk * 16 + r16, N - 1);  // clamped rows are computed but never used
+    const float* wrow = W + (int64_t)n * ldw;
+    // Unconditional loads, addresses clamped into the row (a group past the pass, or a lane past K, re-reads valid
+    // weights of its row: such a group is never multiplied -- the tail chunk is guarded -- and such a lane meets the
+    // image's zero padding).  A load inside a branch, or one whose value goes through a select, hides the count of
+    // outstanding loads from the compiler or drags the load down to its use: either way the prefetch of the next
+    // chunk was waited for before the first MFMA of every chunk.
+    auto loadw = [&](int g, int g_hi) -> f32x4 {
+        const int k = 16 * min(g, g_hi - 1) + 4 * kq;
+        return SK_LOADW(wrow + min(k, K - 4));
+    };
+    f32x4 acc[SK64_TILES];
+#pragma unroll
+    for (int t = 0; t < SK64_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* xs = Xs + r16 * Kp + 4 * kq;
+    for (int g_lo = 0; g_lo < nG; g_lo += g_per_pass) {
+        const int g_hi = min(nG, g_lo + g_per_pass);
+        f32x4 cur[GC], nxt[GC];
+#pragma unroll
+        for (int i = 0; i < GC; ++i) cur[i] = loadw(g_lo + i, g_hi);  // in flight while the image is built
+        if (g_lo > 0) __syncthreads();  // every wave is done with the previous pass's image
+        const int k_lo = 16 * g_lo;
+        auto fetch = [&](int r, int kk) {
+            const int m = m0 + r, k = k_lo + kk;
+            if (m >= M || k >= K || kk >= 16 * (g_hi - g_lo)) return make_float4(0.f, 0.f, 0.f, 0.f);
+            return k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
+                          : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
+        };
+        // 16 loads in flight per thread: a pass's image (up to 150 KB) is ONE memory round trip per thread
+        fill_image<SK_THREADS, decltype(fetch), 16>(Xs, SK64_ROWS, Kp, fetch);
+        __syncthreads();
+        if (!active) continue;
+        int g0 = g_lo;
+        for (; g0 + GC <= g_hi; g0 += GC) {
+#pragma unroll
+            for (int i = 0; i < GC; ++i) nxt[i] = loadw(g0 + GC + i, g_hi);
+            __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued before the chunk's MFMAs, not after
+            sk64_chunk<true>(acc, cur, xs, Kp, g0 - g_lo, GC);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GC; ++i) cur[i] = nxt[i];
+        }
+        if (g0 < g_hi) sk64_chunk<false>(acc, cur, xs, Kp, g0 - g_lo, g_hi - g0);
+    }
+#ifdef SK_PROFILE
+    asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        g_skclk[0] = clock64() - c0;
+        g_skclk[1] = wall_clock64() - w0;
+    }
+#endif
+    // lane holds columns nb..nb+3 of activation rows m0 + 16 t + r16
+    float best_v[SK64_TILES];
+    int best_i[SK64_TILES];
+    const int nb = blk * 16 + 4 * kq;
+#pragma unroll
+    for (int t = 0; t < SK64_TILES; ++t) { best_v[t] = SK_NEG; best_i[t] = 0; }
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (nb + r < N) {
+                const float bv = bias ? bias[nb + r] : 0.f;
+#pragma unroll
+                for (int t = 0; t < SK64_TILES; ++t) {
+                    const float v = acc[t][r] + bv;
+                    if (v > best_v[t]) { best_v[t] = v; best_i[t] = nb + r; }
+                }
+            }
+        }
+    }
+    // best over the 4 lane groups of the wave (ties: the smaller column), then over the 8 waves
+#pragma unroll
+    for (int t = 0; t < SK64_TILES; ++t) {
+        float v = best_v[t];
+        int ix = best_i[t];
+#pragma unroll
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float v2 = __shfl_xor(v, o, 64);
+            const int i2 = __shfl_xor(ix, o, 64);
+            if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        }
+        if (kq == 0) { red_v[wave][t * 16 + r16] = v; red_i[wave][t * 16 + r16] = ix; }
+    }
+    __syncthreads();
+    if (threadIdx.x < SK64_ROWS) {
+        const int m = m0 + threadIdx.x;
+        if (m < M) {
+            float v = red_v[0][threadIdx.x];
+            int ix = red_i[0][threadIdx.x];
+#pragma unroll
+            for (int w = 1; w < SK_WAVES; ++w) {
+                const float v2 = red_v[w][threadIdx.x];
+                const int i2 = red_i[w][threadIdx.x];
+                if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+            }
+            part_max[(int64_t)m * n_split + bx] = v;
+            part_sum[(int64_t)m * n_split + bx] = 1.f;
+            part_arg[(int64_t)m * n_split + bx] = ix;
+        }
+    }
+}
+
 // One GRU cell step for a decode batch, fused: gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh and the gate math
 // (decoder/rnn_decoder.py:61-66 from the greedy loop :160-168) in ONE launch instead of three.  A workgroup owns
 // 16 hidden units for 16 MT batch rows; [x | h] sits in LDS; its twelve waves each stream half the K range of
@@ -363,7 +538,32 @@ int argmax_bpw(int M, int N) {
     return (bpw + SK_WAVES - 1) / SK_WAVES * SK_WAVES;
 }
 
+// 64-row arg-max kernel: k-groups (of 16) per pass so that the [64][16 g + 4] image fits the LDS budget; used for
+// decode batches of more than one 32-row chunk.  DSSVAE_SKINNY_ROWS=32 keeps the 32-row kernel (A/B, tests).
+struct Plan64 { int g_per_pass, Kp, n_split; bool use; };
+Plan64 plan64(int M, int N, int K) {
+    Plan64 p;
+    const int nG = (K + 15) / 16;
+    const int g_max = (SK_LDS_BUDGET / (SK64_ROWS * 4) - 4) / 16;  // groups whose image fits
+    const int n_pass = (nG + g_max - 1) / g_max;
+    p.g_per_pass = (nG + n_pass - 1) / n_pass;
+    p.Kp = 16 * p.g_per_pass + 4;
+    p.n_split = ((N + 15) / 16 + SK_WAVES - 1) / SK_WAVES;
+    const char* f = getenv("DSSVAE_SKINNY_ROWS");
+    // a wave owns one 16-column block: only vocabularies that give every CU a workgroup or so (the 30k sentence
+    // vocabulary: 235) -- the 300-symbol tree vocabulary is 3 workgroups per row chunk and stays with the 32-row kernel
+    p.use = M > SK_ROWS && !(f && atoi(f) == 32) &&
+            p.n_split * ((M + SK64_ROWS - 1) / SK64_ROWS) >= sk_cus() / 2;
+    return p;
+}
+
 }  // namespace
+
+#ifdef SK_PROFILE
+extern "C" int dssvae_skinny_profile_read(unsigned long long* dst_host) {
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_skclk), sizeof(g_skclk), 0, hipMemcpyDeviceToHost);
+}
+#endif
 
 extern "C" int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int64_t ldw) {
     // alignment of the pointers is checked at the call; this answers for the shape
@@ -374,6 +574,10 @@ extern "C" int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64
 
 extern "C" int dssvae_skinny_argmax_splits(int M, int N) {
     if (M <= 0 || N <= 0) return DSSVAE_EINVAL;
+    if (M > SK_ROWS) {  // the 64-row kernel's split count does not depend on K
+        const Plan64 p = plan64(M, N, 16);
+        if (p.use) return p.n_split;
+    }
     const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
     return (NB + bpw - 1) / bpw;
 }
@@ -391,6 +595,11 @@ extern "C" int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const 
                                 nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
+extern "C" int dssvae_skinny_argmax_rows(int M, int N) {
+    if (M <= 0 || N <= 0) return DSSVAE_EINVAL;
+    return plan64(M, N, 16).use ? SK64_ROWS : SK_ROWS;
+}
+
 extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                                     const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
                                     float* part_sum, int64_t* part_arg, void* stream) {
@@ -398,6 +607,17 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
         (K2 > 0 && !X2) || ld1 < K1 || ldw < K1 + K2 || (K2 > 0 && ld2 < K2))
         return DSSVAE_EINVAL;
     if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
+    const Plan64 p64 = plan64(M, N, K1 + K2);
+    if (p64.use) {
+        const int lds = SK64_ROWS * p64.Kp * 4, m_chunks = (M + SK64_ROWS - 1) / SK64_ROWS;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_argmax64_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(skinny_argmax64_kernel, dim3(((p64.n_split + 7) / 8) * 8 * m_chunks), dim3(SK_THREADS), lds,
+                           (hipStream_t)stream, X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, p64.Kp, p64.g_per_pass,
+                           part_max, part_sum, part_arg, p64.n_split, m_chunks);
+        DSSVAE_CHECK_LAUNCH();
+        return DSSVAE_OK;
+    }
     const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
     return sk_launch<true, 1>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
                            part_max, part_sum, part_arg, (hipStream_t)stream);

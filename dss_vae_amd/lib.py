@@ -101,6 +101,7 @@ _SIGNATURES = {
     "dssvae_lstm_step_bwd": ([_P, _L, _P, _L, _P, _P, _P, _I, _I, _I, _P, _L, _P, _P, _P], _I),
     "dssvae_skinny_supported": ([_I, _I, _I, _L, _L, _L], _I),
     "dssvae_skinny_argmax_splits": ([_I, _I], _I),
+    "dssvae_skinny_argmax_rows": ([_I, _I], _I),
     "dssvae_skinny_linear": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P], _I),
     "dssvae_skinny_gru_step": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_skinny_argmax": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _P, _P, _P], _I),

@@ -326,6 +326,10 @@ int dssvae_lstm_step_bwd(const float* gates_t, int64_t gates_row_stride, const f
  * alignment to 4 floats, LDS budget): the caller then uses dssvae_gemm_f32 / dssvae_linear_lse_fwd. */
 #define DSSVAE_SKINNY_MAX_ROWS 128
 int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int64_t ldw);
+/* Activation rows per workgroup of the kernel dssvae_skinny_argmax runs for this shape: 32 (skinny_kernel<ARGMAX>) or
+ * 64 (skinny_argmax64_kernel: decode batches above 32 rows over a vocabulary large enough to give every CU a workgroup).
+ * The MFMA work of a launch is the decode batch padded to a multiple of it.  No reference counterpart. */
+int dssvae_skinny_argmax_rows(int M, int N);
 int dssvae_skinny_argmax_splits(int M, int N);
 int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* C, int64_t ldc,

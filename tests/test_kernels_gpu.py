@@ -442,7 +442,8 @@ def test_native_greedy_decode_loop(B, E, H, V, layers, T):
     close(hf, torch.stack(h, 0), rtol=1e-4, atol=1e-4, what="h_final")
 
 
-@pytest.mark.parametrize("M,K1,K2,N", [(1, 4, 0, 5), (50, 600, 300, 3001), (33, 300, 0, 1800), (128, 20, 12, 97)])
+@pytest.mark.parametrize("M,K1,K2,N", [(1, 4, 0, 5), (50, 600, 300, 3001), (33, 300, 0, 1800), (128, 20, 12, 97),
+                                      (64, 600, 300, 30000), (100, 800, 300, 20000)])  # 64-row arg-max (2 k passes; 1 and 2 row chunks)
 def test_skinny_linear_and_argmax(M, K1, K2, N):
     """C-ABI skinny kernels (decode-batch sized M) vs fp64 torch"""
     from dss_vae_amd import lib as L
