@@ -17,9 +17,9 @@
 // A launch may cover steps [t0, t0 + T) of a longer recurrence (inst.t0 / T_total): the caller cuts a launch in
 // time where its short recurrences end, so that the long ones continue in finer cells (ops._segments).
 // Measured where a step goes (tools/gru_phases.py, -DGRU_PROFILE build; 2 x B256 H300, 64-row cells, KS = 4):
-// 7.9 us = counter match 2.0 | exchange loads + own products 2.0 | partial sums of the other parts 1.4 |
-// gate math 0.05 | state store drained 1.2 | signal 0.6 | history stores 0.8 -- four dependent memory round
-// trips per step; the arithmetic is a quarter of it.
+// 7.5 us = counter match 1.7 | exchange loads + own products 1.8 | partial sums of the other parts 1.5 |
+// gate math 0.04 | state store drained 1.25 | signal 0.5 | history stores 0.8 -- four dependent memory round
+// trips per step; the arithmetic is a quarter of it (profiles/r02_z_gru_phases.txt).
 // Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first table row): EVERY byte of
 // the exchange buffer is stored write-through (buffer_store_dwordx4 sc1) and EVERY load of it is a
 // buffer_load_dwordx4 sc1 (bypasses the CU's L1), so no release / acquire cache maintenance is
