@@ -211,6 +211,35 @@ __device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, in
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[g * gate_stride + c * 64], xv[c], acc[g], 0, 0, 0);
 }
 
+// N consecutive slices, branch-free, with the W fragments of slice i+1 read from LDS BEFORE the MFMAs of slice i (two
+// register sets in rotation): the LDS latency of a slice hides under the previous slice's MFMAs instead of stalling
+// the matrix pipe once per slice.
+template <int NG, int N>
+__device__ __forceinline__ void mfma_slices(f32x4 (&acc)[NG], const float* Wl, int gate_stride, const f32x4 (&xv)[N]) {
+    // k-steps of N slices in one stream; the W fragments of step s + 2 are read from LDS while step s runs (a ring of
+    // three steps: 3 * NG registers, where whole-slice double buffering spilled the 16-wave layouts)
+    constexpr int S = N * 4;
+    float w[3][NG];
+#pragma unroll
+    for (int s = 0; s < 2 && s < S; ++s)
+#pragma unroll
+        for (int g = 0; g < NG; ++g) w[s][g] = Wl[(s / 4) * 256 + g * gate_stride + (s % 4) * 64];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        if (s + 2 < S) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+                w[(s + 2) % 3][g] = Wl[((s + 2) / 4) * 256 + g * gate_stride + ((s + 2) % 4) * 64];
+        }
+        // the order is pinned step by step (the scheduler otherwise chains the 4 MFMAs of an accumulator back to
+        // back, each waiting for the one before, and pairs every LDS read with a wait): NG independent MFMAs per k
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s % 3][g], xv[s / 4][s % 4], acc[g], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // WV waves per workgroup: 4 (64 batch rows) or 8 (128 rows: half the workgroups per recurrence, two waves per
 // SIMD share the resident slice -- what lets every decoder of a layer share ONE co-resident launch)
@@ -326,17 +355,23 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         f32x4 cur[CHF], nxt[CHF];
 #pragma unroll
         for (int i = 0; i < CHF; ++i) cur[i] = ld_sc1(rin, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
-        for (int s0 = 0; s0 < s_n; s0 += CHF) {
-            if (s0 + CHF < s_n) {
+        // Full chunks with another chunk behind them: prefetch UNCONDITIONALLY (a load inside a branch hides the
+        // number of outstanding loads from the compiler, which then waits for all of them -- the prefetch included
+        // -- before the chunk's first MFMA) and multiply without per-slice branches (the LDS reads of the slice
+        // move ahead of the MFMAs that hide them).  The last chunk, with nothing in flight behind it, is guarded.
+        int s0 = 0;
+        for (; s0 + CHF < s_n; s0 += CHF) {
 #pragma unroll
-                for (int i = 0; i < CHF; ++i) nxt[i] = ld_sc1(rin, voff + (s0 + CHF + i) * BLK * 4, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < CHF; ++i)
-                if (s0 + i < s_n) mfma_chunk<NG>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
+            for (int i = 0; i < CHF; ++i) nxt[i] = ld_sc1(rin, voff + (s0 + CHF + i) * BLK * 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_slices<NG, CHF>(acc, Wl + s0 * 256, gate_stride, cur);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CHF; ++i) cur[i] = nxt[i];
         }
+#pragma unroll
+        for (int i = 0; i < CHF; ++i)
+            if (s0 + i < s_n) mfma_chunk<NG>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
         if (!lead) {
 #ifdef GRU_PROFILE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
@@ -586,23 +621,44 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         f32x4 cur[CB], nxt[CB];
 #pragma unroll
         for (int i = 0; i < CB; ++i) cur[i] = ld_sc1(rcur, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
-        for (int q0 = 0; q0 < q_n; q0 += CB) {
-            if (q0 + CB < q_n) {
+        // as in gru_fwd_kernel: unconditional prefetch + branch-free full chunks, guarded last chunk
+        int q0 = 0;
+        for (; q0 + CB < q_n; q0 += CB) {
 #pragma unroll
-                for (int i = 0; i < CB; ++i) nxt[i] = ld_sc1(rcur, voff + (q0 + CB + i) * BLK * 4, 0);
-            }
+            for (int i = 0; i < CB; ++i) nxt[i] = ld_sc1(rcur, voff + (q0 + CB + i) * BLK * 4, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                // three independent accumulators in rotation hide the 40-cycle dependent latency; the W fragments
+                // of block i+1 are read from LDS before the MFMAs of block i (see mfma_slices)
+                const float* wb = Wl + q0 * 256;
+                float w[2][4];
 #pragma unroll
-            for (int i = 0; i < CB; ++i)
-                if (q0 + i < q_n) {
-                    // three independent accumulators in rotation hide the 40-cycle dependent latency
-                    const float* w = Wl + (q0 + i) * 256;
+                for (int c = 0; c < 4; ++c) w[0][c] = wb[c * 64];
+#pragma unroll
+                for (int i = 0; i < CB; ++i) {
+                    if (i + 1 < CB) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) w[(i + 1) & 1][c] = wb[(i + 1) * 256 + c * 64];
+                    }
                     f32x4& a = acc[i % 3];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * 64], cur[i][c], a, 0, 0, 0);
+                    for (int c = 0; c < 4; ++c)
+                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i & 1][c], cur[i][c], a, 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);  // blocks stay in order: consecutive blocks use different accumulators
                 }
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CB; ++i) cur[i] = nxt[i];
         }
+#pragma unroll
+        for (int i = 0; i < CB; ++i)
+            if (q0 + i < q_n) {
+                const float* w = Wl + (q0 + i) * 256;
+                f32x4& a = acc[i % 3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * 64], cur[i][c], a, 0, 0, 0);
+            }
         f32x4 sum = acc[0] + acc[1] + acc[2];
         if (!lead) {
             parts[(slot0 + kp - 1) * 64 + lane] = sum;
