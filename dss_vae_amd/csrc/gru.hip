@@ -28,8 +28,9 @@
 // then the wave issues its sc1 loads (every byte it reads was stored by a wave that signalled after
 // its own drain).
 // The exchange loads go through a buffer resource that ends with the batch block's half of the ping-pong, with the
-// slice offset in the VGPR offset: a load past the last slice is out of range and returns zeros without a fetch
-// (the prefetch chunks need no clamping -- clamped duplicates cost 6 % of a backward launch).
+// slice offset in the VGPR offset.  Register-chunk slots past a wave's part are clamped to the part's last slice, NOT
+// left to the range check: an out-of-range load returns its zeros ahead of older loads still in flight, which breaks
+// the in-order assumption behind s_waitcnt vmcnt(n > 0) (see the forward loop).
 // All workgroups of a launch must be co-resident: the host caps the grid at the CU count (1
 // workgroup per CU); every spin is bounded and reports through an error word instead of hanging.
 //
@@ -92,8 +93,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 __device__ __forceinline__ f32x4 ld_sc1(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 16));
 }
+// The store's scalar offset goes into the VGPR offset, soffset stays the literal 0: with an SGPR there the compiler
+// takes a 128-bit buffer store to be free of the "store data overwritten right after issue" hazard and schedules no
+// wait states -- on gfx950 the data registers of four back-to-back stores rewritten in between (what the register
+// allocator chose for the LSTM backward) reached memory partly overwritten: a run-to-run varying error of the
+// exchanged gate gradients.  With a literal soffset it inserts the wait states itself.
 __device__ __forceinline__ void st_sc1(f32x4 v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff, soff, 16);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, v), r, voff + soff, 0, 16);
 }
 
 // Hand-off at WAVE granularity: wave w of a workgroup owns batch rows 16w..16w+15 of its block and needs,
@@ -200,22 +206,12 @@ __device__ __forceinline__ void store4(float* p, const float (&v)[4], bool vec, 
     }
 }
 
-// acc[g] += W_g[16 units][16 k of chunk] . X[16 k][16 rows]; Wc: this chunk's LDS image [4 c][4 kq][16 j]
-// xv: the lane's 4 k-values (k = 4*kq + c) of its batch row
-template <int NG>
-__device__ __forceinline__ void mfma_chunk(f32x4 (&acc)[NG], const float* Wl, int gate_stride, f32x4 xv) {
-#pragma unroll
-    for (int c = 0; c < 4; ++c)
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-            acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wl[g * gate_stride + c * 64], xv[c], acc[g], 0, 0, 0);
-}
-
-// N consecutive slices, branch-free, with the W fragments of slice i+1 read from LDS BEFORE the MFMAs of slice i (two
-// register sets in rotation): the LDS latency of a slice hides under the previous slice's MFMAs instead of stalling
-// the matrix pipe once per slice.
-template <int NG, int N>
-__device__ __forceinline__ void mfma_slices(f32x4 (&acc)[NG], const float* Wl, int gate_stride, const f32x4 (&xv)[N]) {
+// acc[g] += W_g[16 units][16 k of slice] . X[16 k][16 rows] over N consecutive slices; Wl: the LDS image, per slice
+// [4 c][4 kq][16 j]; xv[i]: the lane's 4 k-values (k = 4*kq + c) of its batch row in slice i.  Branch-free, the W
+// fragments read from LDS ahead of the MFMAs that use them: the LDS latency hides under the matrix pipe instead of
+// stalling it once per slice.
+template <int NG, int N, int M>
+__device__ __forceinline__ void mfma_slices(f32x4 (&acc)[NG], const float* Wl, int gate_stride, const f32x4 (&xv)[M]) {
     // k-steps of N slices in one stream; the W fragments of step s + 2 are read from LDS while step s runs (a ring of
     // three steps: 3 * NG registers, where whole-slice double buffering spilled the 16-wave layouts)
     constexpr int S = N * 4;
@@ -237,6 +233,42 @@ __device__ __forceinline__ void mfma_slices(f32x4 (&acc)[NG], const float* Wl, i
         for (int g = 0; g < NG; ++g)
             acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s % 3][g], xv[s / 4][s % 4], acc[g], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// the first n (1 .. M, wave-uniform) slices of xv: the branch-free stream of exactly that length
+template <int NG, int M, int N = M>
+__device__ __forceinline__ void mfma_tail(f32x4 (&acc)[NG], const float* Wl, int gate_stride, const f32x4 (&xv)[M], int n) {
+    if constexpr (N >= 1) {
+        if (n == N) mfma_slices<NG, N, M>(acc, Wl, gate_stride, xv);
+        else mfma_tail<NG, M, N - 1>(acc, Wl, gate_stride, xv, n);
+    }
+}
+
+// backward: N blocks (16 gate columns each) into three accumulators in rotation; the W fragments of block i + 1 are read
+// from LDS before the MFMAs of block i, blocks stay in order (consecutive blocks use different accumulators)
+template <int N, int M>
+__device__ __forceinline__ void mfma_blocks(f32x4 (&acc)[3], const float* wb, const f32x4 (&xv)[M]) {
+    float w[2][4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) w[0][c] = wb[c * 64];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        if (i + 1 < N) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) w[(i + 1) & 1][c] = wb[(i + 1) * 256 + c * 64];
+        }
+        f32x4& a = acc[i % 3];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i & 1][c], xv[i][c], a, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+template <int M, int N = M>
+__device__ __forceinline__ void mfma_blocks_tail(f32x4 (&acc)[3], const float* wb, const f32x4 (&xv)[M], int n) {
+    if constexpr (N >= 1) {
+        if (n == N) mfma_blocks<N, M>(acc, wb, xv);
+        else mfma_blocks_tail<M, N - 1>(acc, wb, xv, n);
     }
 }
 
@@ -302,8 +334,8 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     float* hx0 = d.hx + (size_t)bblock * NS * BLK;
     float* hx1 = hx0 + (size_t)d.n_bblocks * NS * BLK;
     const __amdgpu_buffer_rsrc_t ws0 = make_rsrc(hx0, half_bytes), ws1 = make_rsrc(hx1, half_bytes);
-    // this wave's part of the slices: a resource of its own, so that loads past the part fetch nothing
-    const int per = (NS + KS - 1) / KS, s_lo = min(NS, kp * per), s_n = min(NS - s_lo, per);
+    // this wave's part of the slices: a resource of its own (an empty part fetches nothing)
+    const int per = (NS + KS - 1) / KS, s_lo = min(NS, kp * per), s_n = min(NS - s_lo, per), s_last = max(s_n - 1, 0);
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(hx0 + (size_t)s_lo * BLK, (unsigned)s_n * BLK * 4u),
                                  rs1 = make_rsrc(hx1 + (size_t)s_lo * BLK, (unsigned)s_n * BLK * 4u);
     const int voff = ((rg * 16 + j) * UU + 4 * kq) * 4;  // same lane offset inside every slice block
@@ -354,24 +386,26 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         for (int g = 0; g < NG; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 cur[CHF], nxt[CHF];
 #pragma unroll
-        for (int i = 0; i < CHF; ++i) cur[i] = ld_sc1(rin, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
+        for (int i = 0; i < CHF; ++i) cur[i] = ld_sc1(rin, voff + min(i, s_last) * BLK * 4, 0);
         // Full chunks with another chunk behind them: prefetch UNCONDITIONALLY (a load inside a branch hides the
         // number of outstanding loads from the compiler, which then waits for all of them -- the prefetch included
         // -- before the chunk's first MFMA) and multiply without per-slice branches (the LDS reads of the slice
-        // move ahead of the MFMAs that hide them).  The last chunk, with nothing in flight behind it, is guarded.
+        // move ahead of the MFMAs that hide them).  Slices past the part are CLAMPED to its last slice (loaded
+        // again, never multiplied), not left to the buffer's range check: an out-of-range buffer load returns its
+        // zeros at once, AHEAD of older loads still in flight, and the compiler's s_waitcnt vmcnt(n > 0) -- which
+        // counts on in-order return -- then releases registers whose loads have not landed (seen as a few-percent,
+        // run-to-run varying error in the LSTM backward, whose block count leaves such a remainder).
         int s0 = 0;
         for (; s0 + CHF < s_n; s0 += CHF) {
 #pragma unroll
-            for (int i = 0; i < CHF; ++i) nxt[i] = ld_sc1(rin, voff + (s0 + CHF + i) * BLK * 4, 0);
+            for (int i = 0; i < CHF; ++i) nxt[i] = ld_sc1(rin, voff + min(s0 + CHF + i, s_last) * BLK * 4, 0);
             __builtin_amdgcn_sched_barrier(0);
-            mfma_slices<NG, CHF>(acc, Wl + s0 * 256, gate_stride, cur);
+            mfma_slices<NG, CHF, CHF>(acc, Wl + s0 * 256, gate_stride, cur);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CHF; ++i) cur[i] = nxt[i];
         }
-#pragma unroll
-        for (int i = 0; i < CHF; ++i)
-            if (s0 + i < s_n) mfma_chunk<NG>(acc, Wl + (s0 + i) * 256, gate_stride, cur[i]);
+        mfma_tail<NG, CHF>(acc, Wl + s0 * 256, gate_stride, cur, s_n - s0);  // the last chunk: 1 .. CHF slices (0: none)
         if (!lead) {
 #ifdef GRU_PROFILE
             asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]));
@@ -514,8 +548,8 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     float* gx0 = d.gx + (size_t)bblock * NQ * BLK;
     float* gx1 = gx0 + (size_t)d.n_bblocks * NQ * BLK;
     const __amdgpu_buffer_rsrc_t ws0 = make_rsrc(gx0, half_bytes), ws1 = make_rsrc(gx1, half_bytes);
-    // this wave's part of the gate blocks: a resource of its own, so that loads past the part fetch nothing
-    const int per = (NQ + KS - 1) / KS, q_lo = min(NQ, kp * per), q_n = min(NQ - q_lo, per);
+    // this wave's part of the gate blocks: a resource of its own (an empty part fetches nothing)
+    const int per = (NQ + KS - 1) / KS, q_lo = min(NQ, kp * per), q_n = min(NQ - q_lo, per), q_last = max(q_n - 1, 0);
     const __amdgpu_buffer_rsrc_t rs0 = make_rsrc(gx0 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u),
                                  rs1 = make_rsrc(gx1 + (size_t)q_lo * BLK, (unsigned)q_n * BLK * 4u);
     const int voff = ((rg * 16 + j) * UU + 4 * kq) * 4;
@@ -528,7 +562,11 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     // bias gradients (column sums of dgx / dgh over batch and time) ride along in registers
     float sb_r[4] = {0.f, 0.f, 0.f, 0.f}, sb_z[4] = {0.f, 0.f, 0.f, 0.f}, sb_n[4] = {0.f, 0.f, 0.f, 0.f},
           sb_m[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef GRU_PROFILE
+    const int prof_slot = (wave == 0) ? PROF_SLOT((int)gridDim.x) : -1;
+#endif
     for (int step = 0; step < T; ++step) {
+        PROF(0);
         // backward walks the forward order in reverse: forward steps t0 + T - 1 down to t0 of the recurrence
         const int fstep = in.t0 + T - 1 - step;
         const int t = in.reverse ? Tt - 1 - fstep : fstep;
@@ -590,6 +628,10 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             // then overlap the wait
 #pragma unroll
             for (int c = 0; c < 4; ++c) { sb_r[c] += g0[c]; sb_z[c] += g1[c]; sb_n[c] += g2[c]; sb_m[c] += g3[c]; }
+#ifdef GRU_PROFILE
+            asm volatile("s_nop 0" ::"v"(g0[0]), "v"(g1[0]), "v"(g2[0]), "v"(g3[0]));  // the saved gates are there
+#endif
+            PROF(1);
             st_sc1((f32x4){g0[0], g0[1], g0[2], g0[3]}, wcur, voff, own);
             st_sc1((f32x4){g1[0], g1[1], g1[2], g1[3]}, wcur, voff, own + BLK * 4);
             if constexpr (LSTM) {
@@ -599,6 +641,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                 st_sc1((f32x4){g3[0], g3[1], g3[2], g3[3]}, wcur, voff, own + 2 * BLK * 4);
             }
             publish(cnt);
+            PROF(2);
             if (row_ok && n_ok > 0) {
                 float* ox = in.dgx + bt * K + ub;
                 store4(ox, g0, vec_h, n_ok); store4(ox + H, g1, vec_h, n_ok); store4(ox + 2 * H, g2, vec_h, n_ok);
@@ -609,7 +652,9 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                     store4(oh, g0, vec_h, n_ok); store4(oh + H, g1, vec_h, n_ok); store4(oh + 2 * H, g3, vec_h, n_ok);
                 }
             }
+            PROF(3);
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
+            PROF(4);
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
         } else {
             lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
@@ -620,46 +665,24 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         for (int g = 0; g < 3; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 cur[CB], nxt[CB];
 #pragma unroll
-        for (int i = 0; i < CB; ++i) cur[i] = ld_sc1(rcur, voff + i * BLK * 4, 0);  // past the part: out of range, no fetch
-        // as in gru_fwd_kernel: unconditional prefetch + branch-free full chunks, guarded last chunk
+        for (int i = 0; i < CB; ++i) cur[i] = ld_sc1(rcur, voff + min(i, q_last) * BLK * 4, 0);
+        // as in gru_fwd_kernel: unconditional prefetch, clamped into the part; branch-free chunks
         int q0 = 0;
         for (; q0 + CB < q_n; q0 += CB) {
 #pragma unroll
-            for (int i = 0; i < CB; ++i) nxt[i] = ld_sc1(rcur, voff + (q0 + CB + i) * BLK * 4, 0);
+            for (int i = 0; i < CB; ++i) nxt[i] = ld_sc1(rcur, voff + min(q0 + CB + i, q_last) * BLK * 4, 0);
             __builtin_amdgcn_sched_barrier(0);
-            {
-                // three independent accumulators in rotation hide the 40-cycle dependent latency; the W fragments
-                // of block i+1 are read from LDS before the MFMAs of block i (see mfma_slices)
-                const float* wb = Wl + q0 * 256;
-                float w[2][4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) w[0][c] = wb[c * 64];
-#pragma unroll
-                for (int i = 0; i < CB; ++i) {
-                    if (i + 1 < CB) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) w[(i + 1) & 1][c] = wb[(i + 1) * 256 + c * 64];
-                    }
-                    f32x4& a = acc[i % 3];
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i & 1][c], cur[i][c], a, 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);  // blocks stay in order: consecutive blocks use different accumulators
-                }
-            }
+            mfma_blocks<CB, CB>(acc, Wl + q0 * 256, cur);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < CB; ++i) cur[i] = nxt[i];
         }
-#pragma unroll
-        for (int i = 0; i < CB; ++i)
-            if (q0 + i < q_n) {
-                const float* w = Wl + (q0 + i) * 256;
-                f32x4& a = acc[i % 3];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[c * 64], cur[i][c], a, 0, 0, 0);
-            }
+        mfma_blocks_tail<CB>(acc, Wl + q0 * 256, cur, q_n - q0);  // the last chunk: 1 .. CB blocks (0: none)
         f32x4 sum = acc[0] + acc[1] + acc[2];
+#ifdef GRU_PROFILE
+        asm volatile("s_nop 0" ::"v"(sum));  // the products are there
+#endif
+        if (lead) PROF(5);
         if (!lead) {
             parts[(slot0 + kp - 1) * 64 + lane] = sum;
             lds_signal(done, (unsigned)step + 1u);
@@ -671,6 +694,7 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) dh[c] = dhz[c] + sum[c];
+        PROF(6);
     }
     if (!lead) return;
     if (row_ok && n_ok > 0 && in.dh0) store4(in.dh0 + (size_t)b * H + ub, dh, vec_h, n_ok);

@@ -4,7 +4,10 @@
 Prints, per sampled workgroup, the mean time between the lead wave's phase stamps over the steady-state steps:
     top -> counter matched -> own products done -> partial sums added -> gate math done -> state store drained
     -> signalled -> (history stores issued) next top.
-usage: DSSVAE_LIB=.../libdssvae_prof.so python tools/gru_phases.py N_RECURRENCES B T H"""
+usage: DSSVAE_LIB=.../libdssvae_prof.so python tools/gru_phases.py [--bwd] N_RECURRENCES B T H [B,T,H ...]
+(further B,T,H triples add recurrences of other shapes to the same launch; --bwd stamps the backward kernel instead:
+    top -> saved gates loaded, gate gradients done -> stores issued + published -> history stores issued
+    -> counter matched -> own products done -> partial sums added, next top)"""
 import ctypes as C
 import os
 import sys
@@ -16,32 +19,50 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from dss_vae_amd import lib as L, ops  # noqa: E402
 
 NAMES = ["await", "load+mfma", "reduce", "gates", "store drain", "signal", "history"]
+NAMES_BWD = ["saved gates + math", "stores + publish", "history", "await", "load+mfma", "reduce", "loop"]
 
 
 def main():
-    n, B, T, H = (int(a) for a in sys.argv[1:5])
+    global NAMES
+    argv = sys.argv[1:]
+    bwd = "--bwd" in argv
+    argv = [a for a in argv if a != "--bwd"]
+    n, B, T, H = (int(a) for a in argv[:4])
+    shapes = [(B, T, H)] * n + [tuple(int(v) for v in a.split(",")) for a in argv[4:]]
     dev = "cuda"
     g = torch.Generator().manual_seed(0)
     insts = []
-    for i in range(n):
-        insts.append(dict(xproj=torch.randn(B, T, 3 * H, generator=g).to(dev),
-                          whh=(torch.randn(3 * H, H, generator=g) * 0.05).to(dev),
-                          bhh=torch.randn(3 * H, generator=g).to(dev), h0=torch.randn(B, H, generator=g).to(dev),
-                          group=i, col=0))
+    for i, (b, t, h) in enumerate(shapes):
+        insts.append(dict(xproj=torch.randn(b, t, 3 * h, generator=g).to(dev).requires_grad_(bwd),
+                          whh=(torch.randn(3 * h, h, generator=g) * 0.05).to(dev).requires_grad_(bwd),
+                          bhh=torch.randn(3 * h, generator=g).to(dev).requires_grad_(bwd),
+                          h0=torch.randn(b, h, generator=g).to(dev).requires_grad_(bwd), group=i, col=0))
     lib = L.load()
     lib.dssvae_gru_profile_read.argtypes = [C.c_void_p, C.c_int64]
     buf = np.zeros((4, 128, 8), dtype=np.uint64)
-    with torch.no_grad():
-        for rep in range(3):
+    t0 = torch.cuda.Event(enable_timing=True)
+    t1 = torch.cuda.Event(enable_timing=True)
+    if bwd:
+        NAMES = NAMES_BWD
+        for rep in range(4):
+            outs, _ = ops.gru_layer(insts, save=True)
+            gos = [torch.ones_like(o) for o in outs]
+            torch.cuda.synchronize()
+            t0.record()
+            torch.autograd.backward(outs, gos)
+            t1.record()
+            torch.cuda.synchronize()
+    else:
+        with torch.no_grad():
+            for rep in range(3):
+                ops.gru_layer(insts, save=True)
+            torch.cuda.synchronize()
+            t0.record()
             ops.gru_layer(insts, save=True)
-        torch.cuda.synchronize()
-        t0 = torch.cuda.Event(enable_timing=True)
-        t1 = torch.cuda.Event(enable_timing=True)
-        t0.record()
-        ops.gru_layer(insts, save=True)
-        t1.record()
-        torch.cuda.synchronize()
-    print("launch %.1f us = %.2f us/step" % (t0.elapsed_time(t1) * 1e3, t0.elapsed_time(t1) * 1e3 / T))
+            t1.record()
+            torch.cuda.synchronize()
+    print("%s launch(es) %.1f us = %.2f us/step of the longest" % ("backward" if bwd else "forward",
+          t0.elapsed_time(t1) * 1e3, t0.elapsed_time(t1) * 1e3 / T))
     rc = lib.dssvae_gru_profile_read(buf.ctypes.data, buf.nbytes)
     assert rc == 0, rc
     simd = np.zeros((4, 16), dtype=np.uint32)
@@ -51,7 +72,7 @@ def main():
     part = np.zeros((4, 128, 4), dtype=np.uint64)
     lib.dssvae_gru_profile_part.argtypes = [C.c_void_p]
     assert lib.dssvae_gru_profile_part(part.ctypes.data) == 0
-    steps = min(T, 128)
+    steps = min(min(t for _, t, _ in shapes), 128)
     for w in range(4):
         s = buf[w, 4:steps - 1].astype(np.int64)
         nxt = buf[w, 5:steps, 0].astype(np.int64)
@@ -66,7 +87,7 @@ def main():
                 base = row[1]
                 print("      step %d lead:" % st, " ".join("%+.2f" % ((v - base) / 100.0) for v in row[:8]), "| parts signalled:",
                       " ".join("%+.2f" % ((int(part[pw, st, 3]) - base) / 100.0) for pw in range(1, 4)))
-        for pw in range(1, 4):
+        for pw in range(1, 4 if not bwd else 0):
             pp = part[pw, 4:steps - 1].astype(np.int64)
             if w == 0 and pp[:, 0].min() > 0:
                 # non-lead waves of row group 0 of workgroup 0, relative to the lead's 'counter matched' stamp
