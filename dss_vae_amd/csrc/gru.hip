@@ -36,6 +36,7 @@
 //
 // Roofline: per step 2*B*H*3H flop on fp32 MFMA; in practice latency-bound by the step hand-off.
 #include "common.h"
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -249,19 +250,17 @@ __device__ __forceinline__ void mfma_tail(f32x4 (&acc)[NG], const float* Wl, int
 // from LDS before the MFMAs of block i, blocks stay in order (consecutive blocks use different accumulators)
 template <int N, int M>
 __device__ __forceinline__ void mfma_blocks(f32x4 (&acc)[3], const float* wb, const f32x4 (&xv)[M]) {
-    float w[2][4];
+    // one stream of 4 N k-steps; the W fragment of step s + 3 is read while step s runs (a ring of four registers)
+    constexpr int S = N * 4;
+    float w[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) w[0][c] = wb[c * 64];
+    for (int s = 0; s < 3 && s < S; ++s) w[s] = wb[(s / 4) * 256 + (s % 4) * 64];
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-        if (i + 1 < N) {
-#pragma unroll
-            for (int c = 0; c < 4; ++c) w[(i + 1) & 1][c] = wb[(i + 1) * 256 + c * 64];
-        }
-        f32x4& a = acc[i % 3];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i & 1][c], xv[i][c], a, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < S; ++s) {
+        if (s + 3 < S) w[(s + 3) % 4] = wb[((s + 3) / 4) * 256 + ((s + 3) % 4) * 64];
+        f32x4& a = acc[(s / 4) % 3];
+        a = __builtin_amdgcn_mfma_f32_16x16x4f32(w[s % 4], xv[s / 4][s % 4], a, 0, 0, 0);
+        if ((s % 4) == 3) __builtin_amdgcn_sched_barrier(0);
     }
 }
 template <int M, int N = M>
@@ -359,6 +358,16 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
     if (PROF_SLOT((int)gridDim.x) >= 0 && lane == 0 && wave < 16)
         g_simd[PROF_SLOT((int)gridDim.x)][wave] = __builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
 #endif
+    const float* const xproj_p = in.xproj;
+    const int64_t ldx = in.ldx;
+    const bool fast4 = (H % 4) == 0 && H >= 4 && (ldx % 4) == 0 && (reinterpret_cast<uintptr_t>(xproj_p) % 16) == 0;
+    const bool fast2 = !fast4 && (H % 2) == 0 && H >= 2 && (ldx % 2) == 0 && (reinterpret_cast<uintptr_t>(xproj_p) % 8) == 0;
+    float* const out_p = in.out;
+    float* const hist_p = in.gates;
+    const int64_t ldo = in.ldo;
+    const uintptr_t st_bits = reinterpret_cast<uintptr_t>(out_p) | reinterpret_cast<uintptr_t>(hist_p);
+    const bool fast4s = (H % 4) == 0 && (ldo % 4) == 0 && (st_bits % 16) == 0;
+    const bool fast2s = !fast4s && (H % 2) == 0 && (ldo % 2) == 0 && (st_bits % 8) == 0;
     for (int step = 0; step < T; ++step) {
         PROF(0);
         const int gs = in.t0 + step;  // step of the whole recurrence (this launch runs steps t0 .. t0 + T - 1)
@@ -368,10 +377,30 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
         float xg[NG][4];
         if (lead) {
-            const float* xp = in.xproj + bt * in.ldx;
-            const bool vec_x = vec_h && (in.ldx % 4) == 0;
+            const float* xp = xproj_p + bt * ldx;
+            if (fast4) {
+                // all NG loads back to back, clamped into the row (a lane's pad units are masked by the gate math's
+                // selects): one round trip, where the guarded loads below are waited for one after the other
+                const int uc = min(ub, H - 4);
 #pragma unroll
-            for (int g = 0; g < NG; ++g) load4(xg[g], xp + g * H + ub, vec_x, n_ok);
+                for (int g = 0; g < NG; ++g) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(xp + g * H + uc);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) xg[g][c] = v[c];
+                }
+            } else if (fast2) {
+                const int ua = min(ub, H - 2), uh = min(ub + 2, H - 2);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const f32x2 lo = *reinterpret_cast<const f32x2*>(xp + g * H + ua),
+                                hi = *reinterpret_cast<const f32x2*>(xp + g * H + uh);
+                    xg[g][0] = lo[0]; xg[g][1] = lo[1]; xg[g][2] = hi[0]; xg[g][3] = hi[1];
+                }
+            } else {
+                const bool vec_x = vec_h && (ldx % 4) == 0;
+#pragma unroll
+                for (int g = 0; g < NG; ++g) load4(xg[g], xp + g * H + ub, vec_x, n_ok);
+            }
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             PROF(1);
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
@@ -469,22 +498,30 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             publish(cnt);
         }
         PROF(6);
-        if (row_ok) {
-            store4(in.out + bt * in.ldo + ub, outv, vec_h && (in.ldo % 4) == 0, n_ok);
-            if (in.gates) {
-                float* gs = in.gates + bt * (LSTM ? 7 : 5) * H + ub;
-                store4(gs, v0, vec_h, n_ok);
-                store4(gs + H, v1, vec_h, n_ok);
-                store4(gs + 2 * H, v2, vec_h, n_ok);
-                store4(gs + 3 * H, v3, vec_h, n_ok);
+        // history: every store of the step under ONE predicate per vector width (a lane's 4 units are all inside H
+        // or all pad when H % 4 == 0; two halves when H % 2 == 0), not a branch diamond per store
+        auto store_all = [&](auto st) {
+            st(out_p + bt * ldo + ub, outv);
+            if (hist_p) {
+                float* gs = hist_p + bt * (LSTM ? 7 : 5) * H + ub;
+                st(gs, v0); st(gs + H, v1); st(gs + 2 * H, v2); st(gs + 3 * H, v3);
                 if constexpr (LSTM) {
-                    store4(gs + 4 * H, ccur, vec_h, n_ok);
-                    store4(gs + 5 * H, hcur, vec_h, n_ok);
-                    store4(gs + 6 * H, v4, vec_h, n_ok);
+                    st(gs + 4 * H, ccur); st(gs + 5 * H, hcur); st(gs + 6 * H, v4);
                 } else {
-                    store4(gs + 4 * H, hcur, vec_h, n_ok);
+                    st(gs + 4 * H, hcur);
                 }
             }
+        };
+        if (fast4s) {
+            if (row_ok && ub + 4 <= H)
+                store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x4*>(q) = (f32x4){v[0], v[1], v[2], v[3]}; });
+        } else if (fast2s) {
+            if (row_ok && ub + 2 <= H)
+                store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x2*>(q) = (f32x2){v[0], v[1]}; });
+            if (row_ok && ub + 4 <= H)
+                store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x2*>(q + 2) = (f32x2){v[2], v[3]}; });
+        } else if (row_ok) {
+            store_all([&](float* q, const float (&v)[4]) { store4(q, v, false, n_ok); });
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c) { hcur[c] = hnew[c]; ccur[c] = cnew[c]; }
@@ -501,7 +538,7 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
 template <int WV, bool LSTM>
 __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     constexpr int NTHR = 64 * WV;
-    constexpr int CB = WV > 8 ? 5 : CHB;
+    constexpr int CB = WV > 8 ? (LSTM ? 4 : 5) : CHB;
     constexpr int NG = LSTM ? 4 : 3;
     // chunk q = NG*p + g covers W_hh rows g*H + 16p .. +15; Ws[q][c][kq][i] = whh[g*H + 16p + 4kq + c][u0 + i]
     extern __shared__ __attribute__((aligned(16))) float Ws[];
@@ -565,6 +602,17 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
 #ifdef GRU_PROFILE
     const int prof_slot = (wave == 0) ? PROF_SLOT((int)gridDim.x) : -1;
 #endif
+    const float* const gates_p = in.gates;
+    const float* const dout_p = in.dout;
+    const int64_t ldd = in.ldd;
+    const uintptr_t ptr_bits = reinterpret_cast<uintptr_t>(gates_p) | reinterpret_cast<uintptr_t>(dout_p);
+    const bool fast4 = (H % 4) == 0 && H >= 4 && (dout_p == nullptr || (ldd % 4) == 0) && (ptr_bits % 16) == 0;
+    const bool fast2 = !fast4 && (H % 2) == 0 && H >= 2 && (dout_p == nullptr || (ldd % 2) == 0) && (ptr_bits % 8) == 0;
+    float* const dgx_p = in.dgx;
+    float* const dgh_p = LSTM ? in.dgx : in.dgh;
+    const uintptr_t st_bits = reinterpret_cast<uintptr_t>(dgx_p) | reinterpret_cast<uintptr_t>(dgh_p);
+    const bool fast4s = (H % 4) == 0 && (st_bits % 16) == 0;
+    const bool fast2s = !fast4s && (H % 2) == 0 && (st_bits % 8) == 0;
     for (int step = 0; step < T; ++step) {
         PROF(0);
         // backward walks the forward order in reverse: forward steps t0 + T - 1 down to t0 of the recurrence
@@ -578,6 +626,59 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             float g0[4] = {0.f, 0.f, 0.f, 0.f}, g1[4] = {0.f, 0.f, 0.f, 0.f}, g2[4] = {0.f, 0.f, 0.f, 0.f},
                   g3[4] = {0.f, 0.f, 0.f, 0.f};
             const size_t bt = (size_t)(row_ok ? b : 0) * Tt + t;
+            if (fast4 || fast2) {
+                // Every saved value of the step in ONE memory round trip: unconditional 16-byte (H % 4 == 0) or
+                // 8-byte (H % 2 == 0) loads back to back; a lane's units past H (pad units of the last slice) and
+                // pad rows read a valid, clamped address and are masked afterwards.  The guarded per-value loads of
+                // the general path below cost a round trip EACH -- a load under a branch is waited for at the join
+                // -- which made this phase 3-7 us of every step.
+                const float* grow = gates_p + bt * (LSTM ? 7 : 5) * H;
+                f32x4 r_go, r0, r1, r2, r3, r4, r6;
+                bool vd[4];
+                if (fast4) {
+                    const int uc = min(ub, H - 4);
+                    auto ld = [&](const float* row) { return *reinterpret_cast<const f32x4*>(row + uc); };
+                    r_go = ld(dout_p ? dout_p + bt * ldd : grow);
+                    r0 = ld(grow); r1 = ld(grow + H); r2 = ld(grow + 2 * H); r3 = ld(grow + 3 * H); r4 = ld(grow + 4 * H);
+                    r6 = ld(grow + (LSTM ? 6 : 4) * H);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vd[c] = row_ok && ub + 4 <= H;
+                } else {
+                    const int ua = min(ub, H - 2), uh = min(ub + 2, H - 2);
+                    auto ld = [&](const float* row) {
+                        const f32x2 lo = *reinterpret_cast<const f32x2*>(row + ua), hi = *reinterpret_cast<const f32x2*>(row + uh);
+                        return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+                    };
+                    r_go = ld(dout_p ? dout_p + bt * ldd : grow);
+                    r0 = ld(grow); r1 = ld(grow + H); r2 = ld(grow + 2 * H); r3 = ld(grow + 3 * H); r4 = ld(grow + 4 * H);
+                    r6 = ld(grow + (LSTM ? 6 : 4) * H);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vd[c] = row_ok && ub + (c < 2 ? 2 : 4) <= H;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const bool in_len = t < len;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const bool valid = vd[c], live = valid && in_len;
+                    const float g = dh[c] + (dout_p ? r_go[c] : 0.f);
+                    if constexpr (LSTM) {
+                        const float dct = dc[c] + g * r3[c] * (1.f - r6[c] * r6[c]);
+                        g0[c] = live ? dct * r2[c] * r0[c] * (1.f - r0[c]) : 0.f;
+                        g1[c] = live ? dct * r4[c] * r1[c] * (1.f - r1[c]) : 0.f;
+                        g2[c] = live ? dct * r0[c] * (1.f - r2[c] * r2[c]) : 0.f;
+                        g3[c] = live ? g * r6[c] * r3[c] * (1.f - r3[c]) : 0.f;
+                        dc[c] = live ? dct * r1[c] : dc[c];
+                        dhz[c] = live ? 0.f : (valid ? dh[c] : 0.f);
+                    } else {
+                        const float dn = g * (1.f - r1[c]) * (1.f - r2[c] * r2[c]);
+                        g2[c] = live ? dn : 0.f;
+                        g1[c] = live ? g * (r4[c] - r2[c]) * r1[c] * (1.f - r1[c]) : 0.f;
+                        g0[c] = live ? dn * r3[c] * r0[c] * (1.f - r0[c]) : 0.f;
+                        g3[c] = live ? dn * r0[c] : 0.f;
+                        dhz[c] = live ? g * r1[c] : (valid ? dh[c] : 0.f);
+                    }
+                }
+            } else
             if (row_ok && n_ok > 0) {
                 const bool live = t < len;
                 if (live) {
@@ -642,15 +743,26 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             }
             publish(cnt);
             PROF(2);
-            if (row_ok && n_ok > 0) {
-                float* ox = in.dgx + bt * K + ub;
-                store4(ox, g0, vec_h, n_ok); store4(ox + H, g1, vec_h, n_ok); store4(ox + 2 * H, g2, vec_h, n_ok);
+            auto store_all = [&](auto st) {   // one predicate for all stores of the step (see gru_fwd_kernel)
+                float* ox = dgx_p + bt * K + ub;
+                st(ox, g0); st(ox + H, g1); st(ox + 2 * H, g2);
                 if constexpr (LSTM) {
-                    store4(ox + 3 * H, g3, vec_h, n_ok);
+                    st(ox + 3 * H, g3);
                 } else {
-                    float* oh = in.dgh + bt * K + ub;
-                    store4(oh, g0, vec_h, n_ok); store4(oh + H, g1, vec_h, n_ok); store4(oh + 2 * H, g3, vec_h, n_ok);
+                    float* oh = dgh_p + bt * K + ub;
+                    st(oh, g0); st(oh + H, g1); st(oh + 2 * H, g3);
                 }
+            };
+            if (fast4s) {
+                if (row_ok && ub + 4 <= H)
+                    store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x4*>(q) = (f32x4){v[0], v[1], v[2], v[3]}; });
+            } else if (fast2s) {
+                if (row_ok && ub + 2 <= H)
+                    store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x2*>(q) = (f32x2){v[0], v[1]}; });
+                if (row_ok && ub + 4 <= H)
+                    store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x2*>(q + 2) = (f32x2){v[2], v[3]}; });
+            } else if (row_ok && n_ok > 0) {
+                store_all([&](float* q, const float (&v)[4]) { store4(q, v, false, n_ok); });
             }
             PROF(3);
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
