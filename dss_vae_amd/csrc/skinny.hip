@@ -427,13 +427,16 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const int nG = (Kw + 15) >> 4, gper = (nG + 1) >> 1;
     const int g_lo = khalf * gper, g_hi = min(nG, g_lo + gper);
     // the first weight chunk is on its way while the workgroup builds the [x | h] image
+    // Unconditional loads at clamped addresses (a group past the wave's range is never multiplied; a lane past Kw
+    // meets the image's zero padding): guarded loads came out as a branch each, with a full wait after the second
+    // -- a memory round trip more in a kernel that is three of them long.
+    auto loadw = [&](int g) -> f32x4 {
+        const int k = 16 * min(g, max(g_hi, g_lo + 1) - 1);   // (wrow already carries the lane's 4 * kq)
+        return *reinterpret_cast<const f32x4*>(wrow + max(min(k, Kw - 4 - 4 * kq), -4 * kq));
+    };
     f32x4 cur[SKG_GC], nxt[SKG_GC];
 #pragma unroll
-    for (int i = 0; i < SKG_GC; ++i) {
-        const int g = g_lo + i;
-        const bool ok = g < g_hi && 16 * g + 4 * kq < Kw;
-        cur[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
+    for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
     fill_image<SKG_THREADS>(Xs, ROWS, Kp, [&](int r, int k) {
         const int m = m0 + r;
         if (m < M && k < In) return *reinterpret_cast<const float4*>(X + (int64_t)m * ldx + k);
@@ -447,11 +450,9 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int g0 = g_lo; g0 < g_hi; g0 += SKG_GC) {
+            if (g0 + SKG_GC < g_hi) {   // (wave-uniform; only K ranges beyond one chunk: H > 768)
 #pragma unroll
-            for (int i = 0; i < SKG_GC; ++i) {
-                const int g = g0 + SKG_GC + i;
-                const bool ok = g < g_hi && 16 * g + 4 * kq < Kw;
-                nxt[i] = ok ? *reinterpret_cast<const f32x4*>(wrow + 16 * g) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < SKG_GC; ++i) nxt[i] = loadw(g0 + SKG_GC + i);
             }
 #pragma unroll
             for (int i = 0; i < SKG_GC; ++i) {
