@@ -16,10 +16,16 @@
 //     independent instances / batch blocks / row groups never wait for each other.
 // A launch may cover steps [t0, t0 + T) of a longer recurrence (inst.t0 / T_total): the caller cuts a launch in
 // time where its short recurrences end, so that the long ones continue in finer cells (ops._segments).
-// Measured where a step goes (tools/gru_phases.py, -DGRU_PROFILE build; 2 x B256 H300, 64-row cells, KS = 4):
-// 7.5 us = counter match 1.7 | exchange loads + own products 1.8 | partial sums of the other parts 1.5 |
-// gate math 0.04 | state store drained 1.25 | signal 0.5 | history stores 0.8 -- four dependent memory round
-// trips per step; the arithmetic is a quarter of it (profiles/r02_z_gru_phases.txt).
+// Measured where a step goes (tools/gru_phases.py, -DGRU_PROFILE build; 2 x B256 H300, 64-row cells, KS = 4;
+// profiles/r02_z_gru_phases.txt).  Forward 7.7 us = counter match 2.3 | exchange loads + own products 1.85 | partial
+// sums of the other parts 1.7 | gate math 0.04 | state store drained 1.0 | signal 0.55 | history stores 0.3.
+// Backward 9.8 us = saved values + gate gradients 2.2 | exchange stores + publish 0.9 | history stores 0.2 | counter
+// match 1.9 | exchange loads + own products 3.0 | partial sums 1.4.  Four dependent memory round trips per step; the
+// arithmetic is a quarter of it.  Two rules paid for themselves in these kernels: (1) loads and stores the step waits
+// on are issued back to back without branches -- unconditional loads at clamped addresses masked afterwards, all
+// stores under one predicate -- because a load under a branch is waited for at the join (the backward's seven
+// guarded loads cost a round trip each: 4.4 us of every step, 1.5 now); (2) a 128-bit buffer store takes its scalar
+// offset in the VGPR (see st_sc1).
 // Cross-workgroup visibility (MI355X_MICROARCH.md, "Valid forms", first table row): EVERY byte of
 // the exchange buffer is stored write-through (buffer_store_dwordx4 sc1) and EVERY load of it is a
 // buffer_load_dwordx4 sc1 (bypasses the CU's L1), so no release / acquire cache maintenance is
@@ -28,9 +34,10 @@
 // then the wave issues its sc1 loads (every byte it reads was stored by a wave that signalled after
 // its own drain).
 // The exchange loads go through a buffer resource that ends with the batch block's half of the ping-pong, with the
-// slice offset in the VGPR offset.  Register-chunk slots past a wave's part are clamped to the part's last slice, NOT
-// left to the range check: an out-of-range load returns its zeros ahead of older loads still in flight, which breaks
-// the in-order assumption behind s_waitcnt vmcnt(n > 0) (see the forward loop).
+// slice offset in the VGPR offset.  Register-chunk slots past a wave's part are clamped to the part's last slice
+// (loaded again, never multiplied) rather than left to the range check: every load of the stream then returns through
+// the same path, so the in-order return that s_waitcnt vmcnt(n > 0) counts on does not hang on how the hardware
+// retires an out-of-range load (a precaution -- no failure was traced to it).
 // All workgroups of a launch must be co-resident: the host caps the grid at the CU count (1
 // workgroup per CU); every spin is bounded and reports through an error word instead of hanging.
 //
@@ -419,11 +426,8 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
         // Full chunks with another chunk behind them: prefetch UNCONDITIONALLY (a load inside a branch hides the
         // number of outstanding loads from the compiler, which then waits for all of them -- the prefetch included
         // -- before the chunk's first MFMA) and multiply without per-slice branches (the LDS reads of the slice
-        // move ahead of the MFMAs that hide them).  Slices past the part are CLAMPED to its last slice (loaded
-        // again, never multiplied), not left to the buffer's range check: an out-of-range buffer load returns its
-        // zeros at once, AHEAD of older loads still in flight, and the compiler's s_waitcnt vmcnt(n > 0) -- which
-        // counts on in-order return -- then releases registers whose loads have not landed (seen as a few-percent,
-        // run-to-run varying error in the LSTM backward, whose block count leaves such a remainder).
+        // move ahead of the MFMAs that hide them).  Slices past the part are clamped to its last slice (loaded
+        // again, never multiplied): see the note on the exchange loads at the top of the file.
         int s0 = 0;
         for (; s0 + CHF < s_n; s0 += CHF) {
 #pragma unroll
