@@ -1027,6 +1027,20 @@ extern "C" int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backw
     return DSSVAE_OK;
 }
 
+extern "C" int dssvae_gru_layout(int n_inst, const int32_t* B_host, const int32_t* H_host, const int32_t* rows_host,
+                                 int backward, int cell, int* waves_host) {
+    if (n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !B_host || !H_host || !rows_host || !waves_host ||
+        (cell != DSSVAE_CELL_GRU && cell != DSSVAE_CELL_LSTM))
+        return DSSVAE_EINVAL;
+    for (int i = 0; i < n_inst; ++i)
+        if (B_host[i] <= 0 || H_host[i] <= 0) return DSSVAE_EINVAL;
+    int rows[DSSVAE_GRU_MAX_INST], lds = 0;
+    const int wv = pick_rows(backward != 0, cell == DSSVAE_CELL_LSTM, n_inst, B_host, H_host, rows_host, rows, &lds);
+    if (wv < 0) return DSSVAE_EINVAL;
+    *waves_host = wv;
+    return DSSVAE_OK;
+}
+
 extern "C" int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst, int n_inst, void* workspace, int64_t workspace_bytes,
                               void* stream) {
     if (!inst || n_inst <= 0 || n_inst > DSSVAE_GRU_MAX_INST || !workspace) return DSSVAE_EINVAL;

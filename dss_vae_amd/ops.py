@@ -928,6 +928,108 @@ def _segments(Ts):
     return cuts
 
 
+GRU_SCHEDULE = _os.environ.get("DSSVAE_GRU_SCHEDULE", "1") != "0"   # 0 = time cuts only, the library picks the cells
+_SCHEDULE_CACHE = {}
+
+
+def _step_us(rows, H):
+    """model of a persistent GRU step for the schedule below, fitted to the measured forward steps (5.8 / 7.7 /
+    12.7 / 18.9 us at 1.5 / 3 / 6 / 12 us of MFMA): the hand-off plus the cell's fp32 MFMA time -- rows x 48 gate
+    columns x H on one CU (4 SIMDs x 1024 MAC per 32 cycles, 2.4 GHz) -- which the hand-off only partly hides"""
+    return 4.2 + 1.25 * rows * H * 48 / (128.0 * 2400.0)
+
+
+def _layout_waves(Bs, Hs, rows, backward):
+    """waves per workgroup of the layout the library would choose for such a launch (0 = not resident)"""
+    n = len(Bs)
+    arr = lambda v: (C.c_int32 * n)(*v)
+    out = C.c_int(0)
+    L.check(L.load().dssvae_gru_layout(n, arr(Bs), arr(Hs), arr(rows), backward, L.CELL_GRU, C.byref(out)),
+            "dssvae_gru_layout")
+    return out.value
+
+
+def _schedule(specs):
+    """The launches of one packed group of persistent GRU recurrences, in forward order:
+    [[(position in specs, t0, t1, rows)]] -- every launch runs steps [t0, t1) of its members in cells of `rows`
+    batch rows (0 = the library chooses one height for the launch).  specs = [(B, H, T)].
+
+    The time cuts are those of `_segments`.  On top of them, for the first cut: (1) a recurrence that ends at the
+    cut may run WHOLE in the second launch instead, beside the tails of the long ones (independent recurrences
+    of a launch do not wait for each other), which frees its workgroups in the first launch; (2) the members of a
+    launch may have different cell heights, so that the launch's MFMA-heaviest recurrence -- the one that sets its
+    duration -- gets the finer cells.  Both are chosen by exhaustive search (<= 8 members) under the residency
+    bound of the 16-wave layouts, one workgroup per CU, minimising the summed model time of the two launches.
+    BASELINE configs[1]'s decoder layer [H600 T31 | 2 x H300 T91 | 2 x H300 T31] becomes
+    [H600 in 64-row cells + the long pair's first 31 steps in 128-row cells] then [the long pair's tails in 64-row
+    cells + the short pair whole in 128-row cells]: 228 workgroups each, and the first launch is no longer bound
+    by 12 us of MFMA per step in the H600 cells."""
+    key = (tuple(specs), GRU_SEGMENT_MIN, GRU_SCHEDULE)
+    hit = _SCHEDULE_CACHE.get(key)
+    if hit is not None:
+        return hit
+    segs = _segments([T for _, _, T in specs])
+    plan = [[(j, t0, min(t1, specs[j][2]), 0) for j in members] for t0, t1, members in segs]
+    env = _os.environ
+    tunable = (GRU_SCHEDULE and len(segs) >= 2 and len(specs) <= 8 and not FORCE_STEPWISE_GRU and
+               env.get("DSSVAE_GRU_KSPLIT", "1") != "0" and not env.get("DSSVAE_GRU_WAVES") and
+               # the 16-wave layouts with 64-row cells: the W_hh slice, 12 partial-sum slots of 3 KB, the sync words
+               all(3 * ((H + 15) // 16) * 1024 + 12 * 3 * 1024 + 256 <= 160 * 1024 for _, H, _ in specs))
+    if tunable:
+        cus = n_cus()
+        cut = segs[0][1]
+        long_ = [j for j, (_, _, T) in enumerate(specs) if T > cut]
+        short = [j for j, (_, _, T) in enumerate(specs) if T <= cut]
+        span1 = segs[1][1] - segs[1][0]
+
+        def best_rows(members, steps):
+            """cell heights (64 / 128 per member) of one launch that minimise its model time -> (time, rows)"""
+            best = None
+            for mask in range(1 << len(members)):
+                rows = [64 if (mask >> k) & 1 else 128 for k in range(len(members))]
+                wg = sum(-(-specs[j][0] // r) * -(-specs[j][1] // 16) for j, r in zip(members, rows))
+                if wg > cus:
+                    continue
+                t = max(n * _step_us(r, specs[j][1]) for j, r, n in zip(members, rows, steps))
+                if best is None or (t, wg) < best[:2]:
+                    best = (t, wg, rows)
+            return best
+
+        base0 = best_rows(segs[0][2], [min(cut, specs[j][2]) for j in segs[0][2]])
+        base1 = best_rows(segs[1][2], [min(segs[1][1], specs[j][2]) - cut for j in segs[1][2]])
+        best = None if base0 is None or base1 is None else (base0[0] + base1[0], (), base0[2], base1[2])
+        for mask in range(1, 1 << len(short)):
+            moved = [j for k, j in enumerate(short) if (mask >> k) & 1]
+            m0 = [j for j in segs[0][2] if j not in moved]
+            m1 = list(segs[1][2]) + moved
+            if not m0:
+                continue
+            r0 = best_rows(m0, [min(cut, specs[j][2]) for j in m0])
+            r1 = best_rows(m1, [min(segs[1][1], specs[j][2]) - cut if j not in moved else specs[j][2] for j in m1])
+            if r0 is None or r1 is None:
+                continue
+            # a moved recurrence must not outlast the tails it runs beside (it would lengthen the second launch)
+            if max(specs[j][2] * _step_us(r, specs[j][1]) for j, r in zip(m1, r1[2]) if j in moved) > \
+                    max(span1 * _step_us(r, specs[j][1]) for j, r in zip(m1, r1[2]) if j not in moved) * 1.05:
+                continue
+            if best is None or r0[0] + r1[0] < best[0] - 1e-9:
+                best = (r0[0] + r1[0], tuple(moved), r0[2], r1[2])
+        if best is not None:
+            _, moved, rows0, rows1 = best
+            m0 = [j for j in segs[0][2] if j not in moved]
+            m1 = list(segs[1][2]) + list(moved)
+            tuned = [[(j, 0, min(cut, specs[j][2]), r) for j, r in zip(m0, rows0)],
+                     [(j, 0 if j in moved else cut, specs[j][2] if j in moved else min(segs[1][1], specs[j][2]), r)
+                      for j, r in zip(m1, rows1)]]
+            # the library has the last word (occupancy of the kernels, LDS): both directions of both launches
+            # must come out in the 16-wave layouts the model assumes, or the plan stays with the time cuts
+            if all(_layout_waves([specs[j][0] for j, _, _, _ in e], [specs[j][1] for j, _, _, _ in e],
+                                 [r for _, _, _, r in e], bwd) == 16 for e in tuned for bwd in (0, 1)):
+                plan[0], plan[1] = tuned
+    _SCHEDULE_CACHE[key] = plan
+    return plan
+
+
 _PERSISTENT_ERR = {}
 
 
@@ -1043,25 +1145,25 @@ class _GruFn(Function):
         pers = [i for i in range(n) if fit[i]]
         for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in pers]):
             whole = [pers[k] for k in launch_]
-            for t0, t1, members in _segments([BT[i][1] for i in whole]):
-                launch = [whole[j] for j in members]
+            for entries in _schedule([(BT[i][0], Hs[i], BT[i][1]) for i in whole]):
+                launch = [whole[j] for j, _, _, _ in entries]
                 arr = (L.GruFwdInst * len(launch))()
-                for k, i in enumerate(launch):
+                for k, (i, (_, t0, t1, rows)) in enumerate(zip(launch, entries)):
                     o = outs[meta["group"][i]]
                     assert (o.size(0), o.size(1)) == BT[i]
                     # a later segment continues from the state the previous one left in hl[i] (read and written
-                    # by the same lane: in place); a recurrence that ends inside the segment stops at its own T
+                    # by the same lane: in place)
                     state = h0s[i] if t0 == 0 else hl[i]
                     arr[k] = L.GruFwdInst(
                         xs[i].data_ptr(), _xproj_ld(xs[i]), ws[i].data_ptr(), bs[i].data_ptr(),
                         None if state is None else state.data_ptr(),
                         None if lengths is None else lengths.data_ptr(),
                         o.data_ptr() + 4 * meta["col"][i], o.size(2), hl[i].data_ptr(),
-                        None if gates[i] is None else gates[i].data_ptr(), BT[i][0], min(t1, BT[i][1]) - t0, Hs[i],
-                        int(meta["reverse"][i]), t0, BT[i][1])
+                        None if gates[i] is None else gates[i].data_ptr(), BT[i][0], t1 - t0, Hs[i],
+                        int(meta["reverse"][i]), t0, BT[i][1], rows)
                 wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
                 _note_persistent_error(wsb)
-                steps = [min(t1, BT[i][1]) - t0 for i in launch]
+                steps = [t1 - t0 for _, t0, t1, _ in entries]
                 fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
                 by = sum(4.0 * BT[i][0] * n_t * Hs[i] * (9 if save[i] else 4) for i, n_t in zip(launch, steps))
                 with _PersistentTurn(dev), _Span("gru_fwd_kernel", fl, by, max(steps), detail=" ".join(
@@ -1124,22 +1226,22 @@ class _GruFn(Function):
         for launch_ in _pack([(BT[i][0], Hs[i], BT[i][1]) for i in live_p]):
             whole = [live_p[k] for k in launch_]
             # the forward's segments, last first: d(state) entering a segment is what the later one left in dh0[i]
-            for t0, t1, members in reversed(_segments([BT[i][1] for i in whole])):
-                launch = [whole[j] for j in members]
+            for entries in reversed(_schedule([(BT[i][0], Hs[i], BT[i][1]) for i in whole])):
+                launch = [whole[j] for j, _, _, _ in entries]
                 arr = (L.GruBwdInst * len(launch))()
-                for k, i in enumerate(launch):
+                for k, (i, (_, t0, t1, rows)) in enumerate(zip(launch, entries)):
                     do = douts[meta["group"][i]]
                     dstate = dhl[i] if t1 >= BT[i][1] else dh0[i]
                     arr[k] = L.GruBwdInst(
                         ws[i].data_ptr(), None, None if lengths is None else lengths.data_ptr(), None, 0,
                         gates[i].data_ptr(), None if do is None else do.data_ptr() + 4 * meta["col"][i],
                         0 if do is None else do.size(2), None if dstate is None else dstate.data_ptr(),
-                        dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], min(t1, BT[i][1]) - t0,
+                        dgx[i].data_ptr(), dgh[i].data_ptr(), dh0[i].data_ptr(), BT[i][0], t1 - t0,
                         Hs[i], int(meta["reverse"][i]), None if dbx[i] is None else dbx[i].data_ptr(),
-                        None if dbh[i] is None else dbh[i].data_ptr(), t0, BT[i][1])
+                        None if dbh[i] is None else dbh[i].data_ptr(), t0, BT[i][1], rows)
                 wsb, nbytes = _workspace([BT[i][0] for i in launch], [Hs[i] for i in launch], dev)
                 _note_persistent_error(wsb)
-                steps = [min(t1, BT[i][1]) - t0 for i in launch]
+                steps = [t1 - t0 for _, t0, t1, _ in entries]
                 fl = sum(6.0 * BT[i][0] * n_t * Hs[i] * Hs[i] for i, n_t in zip(launch, steps))
                 by = sum(4.0 * BT[i][0] * n_t * Hs[i] * 12 for i, n_t in zip(launch, steps))
                 with _PersistentTurn(dev), _Span("gru_bwd_kernel", fl, by, max(steps), detail=" ".join(

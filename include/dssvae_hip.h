@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 4 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst */
+#define DSSVAE_ABI_VERSION 5 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -266,6 +266,13 @@ int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int3
  * peers): the runtime's occupancy for the kernel at this LDS slice (largest H of the launch) and block size
  * (largest cell height: 16 rows per wave) x the CU count.  A launch whose grid exceeds it returns DSSVAE_ETOOBIG. */
 int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host);
+/* The layout the library would run a launch of these instances in (no launch): *waves_host = waves per workgroup
+ * (16: the K-split layouts; 4 / 8: one wave per row group), 0 = the grid is not resident with these cell heights.
+ * rows_host[i] as dssvae_gru_*_inst.rows (0 = the library's choice).  For callers that pick cell heights per
+ * instance (dss_vae_amd/ops.py::_schedule) and want to know BEFORE the first launch of a chain whether every launch
+ * of their plan will be admitted.  Host logic of this library: no counterpart in the reference. */
+int dssvae_gru_layout(int n_inst, const int32_t* B_host, const int32_t* H_host, const int32_t* rows_host, int backward,
+                      int cell, int* waves_host);
 int dssvae_gru_fwd(const dssvae_gru_fwd_inst* inst_host, int n_inst, void* workspace,
                    int64_t workspace_bytes, void* stream);
 int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst_host, int n_inst, void* workspace,

@@ -324,6 +324,41 @@ def test_persistent_gru_launch_cut_in_time(reverse, monkeypatch):
         close(outs[i], outs_u[i], rtol=1e-6, atol=1e-6, what="out%d cut vs uncut" % i)
 
 
+def test_persistent_gru_schedule_defers_short_recurrences_and_mixes_cell_heights(monkeypatch):
+    """BASELINE configs[1]'s decoder layer -- [H600 T31 | 2 x H300 T91 | 2 x H300 T31] at batch 256 -- in one gru_layer
+    call: the schedule (ops._schedule) runs the H600 recurrence in 64-row cells beside the first 31 steps of the long
+    pair in 128-row cells, and the short pair WHOLE in the second launch beside the long pair's tails; every output
+    and gradient equals the plain time-cut plan's (one cell height per launch, every recurrence from step 0)"""
+    from dss_vae_amd import ops
+    B, shapes = 256, [(31, 600), (91, 300), (91, 300), (31, 300), (31, 300)]
+    plan = ops._schedule([(B, H, T) for T, H in shapes])
+    assert [sorted(j for j, _, _, _ in e) for e in plan] == [[0, 1, 2], [1, 2, 3, 4]], plan
+    assert {j: r for j, _, _, r in plan[0]} == {0: 64, 1: 128, 2: 128}
+    assert {j: (t0, t1, r) for j, t0, t1, r in plan[1]} == {1: (31, 91, 64), 2: (31, 91, 64), 3: (0, 31, 128),
+                                                             4: (0, 31, 128)}
+    ps = [[rnd(B, T, 3 * H, seed=i), rnd(3 * H, H, seed=10 + i, scale=1.0 / H ** 0.5), rnd(3 * H, seed=20 + i, scale=0.3),
+           rnd(B, H, seed=30 + i)] for i, (T, H) in enumerate(shapes)]
+    gos = [rnd(B, T, H, seed=40 + i) for i, (T, H) in enumerate(shapes)]
+    ghs = [rnd(B, H, seed=50 + i) for i, (T, H) in enumerate(shapes)]
+
+    def run(scheduled):
+        monkeypatch.setattr(ops, "GRU_SCHEDULE", scheduled)
+        dl = [[t.clone().to(DEV).requires_grad_(True) for t in p] for p in ps]
+        insts = [dict(xproj=x, whh=whh, bhh=bhh, h0=h0, group=i, col=0) for i, (x, whh, bhh, h0) in enumerate(dl)]
+        outs, hl = ops.gru_layer(insts, check=True)
+        sum((o * g.to(DEV)).sum() + (h * gh.to(DEV)).sum() for o, h, g, gh in zip(outs, hl, gos, ghs)).backward()
+        ops.check_persistent_errors()
+        return outs, hl, dl
+
+    outs, hl, dl = run(True)
+    outs_p, hl_p, dl_p = run(False)
+    for i in range(len(shapes)):
+        close(outs[i], outs_p[i], rtol=2e-5, atol=2e-5, what="out%d" % i)
+        close(hl[i], hl_p[i], rtol=2e-5, atol=2e-5, what="h_last%d" % i)
+        for name, a, u in zip(("dxproj", "dwhh", "dbhh", "dh0"), dl[i], dl_p[i]):
+            close(a.grad, u.grad, rtol=1e-4, atol=1e-4, what="%s[%d] scheduled vs time cuts only" % (name, i))
+
+
 def test_persistent_gru_grid_one_over_the_residency_bound_is_refused():
     """every workgroup of a persistent launch spins on its peers, so the library admits a grid only up to what the
     chip holds at once (the occupancy answer x CUs: dssvae_gru_resident_workgroups): a grid of exactly that many
