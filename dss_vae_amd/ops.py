@@ -964,13 +964,14 @@ def _schedule(specs):
     [H600 in 64-row cells + the long pair's first 31 steps in 128-row cells] then [the long pair's tails in 64-row
     cells + the short pair whole in 128-row cells]: 228 workgroups each, and the first launch is no longer bound
     by 12 us of MFMA per step in the H600 cells."""
-    key = (tuple(specs), GRU_SEGMENT_MIN, GRU_SCHEDULE)
+    env = _os.environ
+    key = (tuple(specs), GRU_SEGMENT_MIN, GRU_SCHEDULE, FORCE_STEPWISE_GRU, env.get("DSSVAE_GRU_KSPLIT"),
+           env.get("DSSVAE_GRU_WAVES"))
     hit = _SCHEDULE_CACHE.get(key)
     if hit is not None:
         return hit
     segs = _segments([T for _, _, T in specs])
     plan = [[(j, t0, min(t1, specs[j][2]), 0) for j in members] for t0, t1, members in segs]
-    env = _os.environ
     tunable = (GRU_SCHEDULE and len(segs) >= 2 and len(specs) <= 8 and not FORCE_STEPWISE_GRU and
                env.get("DSSVAE_GRU_KSPLIT", "1") != "0" and not env.get("DSSVAE_GRU_WAVES") and
                # the 16-wave layouts with 64-row cells: the W_hh slice, 12 partial-sum slots of 3 KB, the sync words
