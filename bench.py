@@ -300,6 +300,7 @@ def main():
     for _ in range(a.steps):
         it += 1
         ret = train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
+    host_dt = time.perf_counter() - t0   # every launch of the K steps is enqueued: the host's share of a step
     sync()
     dt = time.perf_counter() - t0
     ops.PROFILE = None
@@ -319,7 +320,7 @@ def main():
             "metric": "train sentences/sec (fwd+bwd) DSS-VAE", "value": a.batch * world * a.steps / dt,
             "unit": "sentences/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": 1e3 * dt / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "host_enqueue_ms_per_step": 1e3 * host_dt / a.steps,
             "config": {"workload": "BASELINE configs[%d]: full DSS-VAE (%s) %sfwd+bwd+clip+Adam, vocab %d, tree vocab %d, "
                                    "src len %d, tree len %d%s, batch %d per GPU, E=%d H=%d Z=%d, fp32"
                                    % (3 if a.stress else 1, a.model,
