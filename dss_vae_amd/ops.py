@@ -979,7 +979,6 @@ def _schedule(specs):
     if tunable:
         cus = n_cus()
         cut = segs[0][1]
-        long_ = [j for j, (_, _, T) in enumerate(specs) if T > cut]
         short = [j for j, (_, _, T) in enumerate(specs) if T <= cut]
         span1 = segs[1][1] - segs[1][0]
 
