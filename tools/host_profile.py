@@ -13,3 +13,6 @@ s = io.StringIO()
 st = pstats.Stats(pr, stream=s).sort_stats('tottime')
 st.print_stats(45)
 print(s.getvalue()[:9000])
+s2 = io.StringIO()
+pstats.Stats(pr, stream=s2).sort_stats('cumulative').print_stats('ops.py|parallel.py|train.py|rnn_|syntax_vae', 40)
+print(s2.getvalue()[:9000])
