@@ -496,8 +496,10 @@ import os as _os
 # dlogits slab of one row chunk.  Measured on the headline workload (bench.py --shapes, DSSVAE_SLAB_MB sweep):
 # 128 MiB (inside the 256 MiB Infinity Cache) 5.88k sentences/s, 256 MiB 6.02k, 512 MiB 6.09k -- the consumers
 # of the slab are MFMA-bound GEMMs that take it from HBM just as well, while longer chunks quantise better
-# over the chip (LSE: 3.67 -> 14.2 rounds of workgroups) and pass over dW fewer times.
-SLAB_BYTES = int(_os.environ.get("DSSVAE_SLAB_MB", "512")) << 20
+# over the chip (LSE: 3.67 -> 14.2 rounds of workgroups) and pass over dW fewer times.  Round 2: 1024 MiB holds the
+# headline's 7936 x 30000 logits in ONE chunk (28.5 rounds, dW written once): 31.05 -> 30.82 ms per step; 288 GB of HBM
+# make a gigabyte of scratch per process a small price.
+SLAB_BYTES = int(_os.environ.get("DSSVAE_SLAB_MB", "1024")) << 20
 
 
 def _col_chunks(M, N):
