@@ -473,6 +473,20 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&part[wave][mt][lane][0]) = acc[mt];
     }
+    // the cell's biases for the waves that apply it: all 24 loads back to back at clamped indices BEFORE the barrier
+    // (one memory round trip under the wait for the other waves; guarded loads inside the per-unit branches below
+    // were a round trip per unit)
+    float bi[3][4], bh[3][4];
+    if (wave < MT) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int u = min(u0 + 4 * kq + c, H - 1);
+                bi[g][c] = bih[g * H + u];
+                bh[g][c] = bhh[g * H + u];
+            }
+    }
     __syncthreads();
     if (wave < MT) {
         // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16; k halves added low + high
@@ -488,9 +502,9 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
             const int u = u0 + 4 * kq + c;
             if (m < M && u < H) {
                 // same association as the unfused path: (x W^T + b_ih) + (h W^T + b_hh)
-                const float r = sk_sigm((pre[0][c] + bih[u]) + (pre[1][c] + bhh[u]));
-                const float z = sk_sigm((pre[2][c] + bih[H + u]) + (pre[3][c] + bhh[H + u]));
-                const float n = tanhf((pre[4][c] + bih[2 * H + u]) + r * (pre[5][c] + bhh[2 * H + u]));
+                const float r = sk_sigm((pre[0][c] + bi[0][c]) + (pre[1][c] + bh[0][c]));
+                const float z = sk_sigm((pre[2][c] + bi[1][c]) + (pre[3][c] + bh[1][c]));
+                const float n = tanhf((pre[4][c] + bi[2][c]) + r * (pre[5][c] + bh[2][c]));
                 Hn[(int64_t)m * ldo + u] = (1.f - z) * n + z * hold[u];
             }
         }
