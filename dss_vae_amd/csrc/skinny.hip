@@ -553,6 +553,16 @@ int argmax_bpw(int M, int N) {
     return (bpw + SK_WAVES - 1) / SK_WAVES * SK_WAVES;
 }
 
+// Small vocabularies (the 300-symbol tree vocabulary: 19 blocks) leave a wave ONE block with the whole K range behind it:
+// a chain of K / 256 memory round trips (3 at K = 600; 20 us per launch for 0.7 MB of weights).  While the launch
+// stays within a workgroup per CU, four waves share a block instead (KS = 4: a quarter of the chain each, partials
+// summed through LDS, as in the gate products) and a workgroup takes 2 blocks.
+constexpr int SK_ARGMAX_KS = 4;
+bool argmax_ksplit(int M, int N) {
+    const int NB = (N + 15) / 16, m_chunks = (M + SK_ROWS - 1) / SK_ROWS, slots = SK_WAVES / SK_ARGMAX_KS;
+    return (NB + slots - 1) / slots * m_chunks <= sk_cus();
+}
+
 // 64-row arg-max kernel: k-groups (of 16) per pass so that the [64][16 g + 4] image fits the LDS budget; used for
 // decode batches of more than one 32-row chunk.  DSSVAE_SKINNY_ROWS=32 keeps the 32-row kernel (A/B, tests).
 struct Plan64 { int g_per_pass, Kp, n_split; bool use; };
@@ -593,7 +603,8 @@ extern "C" int dssvae_skinny_argmax_splits(int M, int N) {
         const Plan64 p = plan64(M, N, 16);
         if (p.use) return p.n_split;
     }
-    const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
+    const int NB = (N + 15) / 16;
+    const int bpw = argmax_ksplit(M, N) ? SK_WAVES / SK_ARGMAX_KS : argmax_bpw(M, N);
     return (NB + bpw - 1) / bpw;
 }
 
@@ -633,7 +644,13 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
         DSSVAE_CHECK_LAUNCH();
         return DSSVAE_OK;
     }
-    const int NB = (N + 15) / 16, bpw = argmax_bpw(M, N);
+    const int NB = (N + 15) / 16;
+    if (argmax_ksplit(M, N)) {
+        constexpr int bpw = SK_WAVES / SK_ARGMAX_KS;
+        return sk_launch<true, SK_ARGMAX_KS>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw,
+                                             nullptr, 0, part_max, part_sum, part_arg, (hipStream_t)stream);
+    }
+    const int bpw = argmax_bpw(M, N);
     return sk_launch<true, 1>(X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, bpw, (NB + bpw - 1) / bpw, nullptr, 0,
                            part_max, part_sum, part_arg, (hipStream_t)stream);
 }
