@@ -229,6 +229,10 @@ constexpr int SK64_ROWS = 64, SK64_TILES = 4;
 // development build: shader-clock and 100 MHz wall-clock ticks of workgroup 0's wave 0 over the kernel -> the clock
 // the chip actually runs the generation loop at
 __device__ unsigned long long g_skclk[2];
+__device__ unsigned long long g_skg[8];   // skinny_gru_kernel, workgroup 0 wave 0: 100 MHz stamps of its phases
+#define SKG_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_skg[i] = wall_clock64(); } while (0)
+#else
+#define SKG_STAMP(i) do {} while (0)
 #endif
 
 #ifdef SK_NO_LOAD   // development: the matrix work alone (no weight stream)
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp, int g_per_pass,
     float* __restrict__ part_max, float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split,
     int m_chunks) {
-    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [64][Kp]: the k range of the current pass
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [64][Kp]: the k range of the current pass; + 4 spare
     __shared__ float red_v[SK_WAVES][SK64_ROWS];
     __shared__ int red_i[SK_WAVES][SK64_ROWS];
     constexpr int GC = SK64_GC;
@@ -303,21 +307,54 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
 #pragma unroll
     for (int t = 0; t < SK64_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xs = Xs + r16 * Kp + 4 * kq;
+    constexpr int TPR = SK_THREADS / SK64_ROWS, IU = 16;
+    const int kp4 = Kp >> 2;
+    const int ir = threadIdx.x / TPR, ic = threadIdx.x % TPR;
+    const bool row_ok = m0 + ir < M;
+    const float* x1row = X1 + (int64_t)min(m0 + ir, M - 1) * ld1;
+    const float* x2row = K2 > 0 ? X2 + (int64_t)min(m0 + ir, M - 1) * ld2 : x1row;
     for (int g_lo = 0; g_lo < nG; g_lo += g_per_pass) {
         const int g_hi = min(nG, g_lo + g_per_pass);
         f32x4 cur[GC], nxt[GC];
+        // The pass's image: a thread owns one row and every TPR-th 16-byte column of it -- no division by a run-time
+        // value and no branch around a load (clamped addresses, masked when stored; a column past the row goes to
+        // the spare 16 bytes behind the image, so that the store is unconditional and its load cannot sink into a
+        // branch).  Order: image loads, then a barrier that waits for no memory (every wave has issued its image
+        // loads and is done with the previous pass's image), then the first weight chunk, in flight while the
+        // image is stored -- loads return in order, so the image is not queued behind other waves' weights.
+        const int k_lo = 16 * g_lo, kvalid = min(16 * (g_hi - g_lo), K - k_lo);
+        auto img_load = [&](int c0, f32x4* v) {
 #pragma unroll
-        for (int i = 0; i < GC; ++i) cur[i] = loadw(g_lo + i, g_hi);  // in flight while the image is built
-        if (g_lo > 0) __syncthreads();  // every wave is done with the previous pass's image
-        const int k_lo = 16 * g_lo;
-        auto fetch = [&](int r, int kk) {
-            const int m = m0 + r, k = k_lo + kk;
-            if (m >= M || k >= K || kk >= 16 * (g_hi - g_lo)) return make_float4(0.f, 0.f, 0.f, 0.f);
-            return k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
-                          : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
+            for (int u = 0; u < IU; ++u) {
+                const int kc = min(k_lo + 4 * (c0 + ic + u * TPR), K - 4);
+                v[u] = *reinterpret_cast<const f32x4*>(kc < K1 ? x1row + kc : x2row + (kc - K1));
+            }
         };
-        // 16 loads in flight per thread: a pass's image (up to 150 KB) is ONE memory round trip per thread
-        fill_image<SK_THREADS, decltype(fetch), 16>(Xs, SK64_ROWS, Kp, fetch);
+        auto img_store = [&](int c0, const f32x4* v) {
+#pragma unroll
+            for (int u = 0; u < IU; ++u) {
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const int c = c0 + ic + u * TPR, kk = 4 * c;
+                const unsigned keep = row_ok && kk < kvalid ? 0xffffffffu : 0u;
+                *reinterpret_cast<u32x4*>(__builtin_assume_aligned(Xs + (c < kp4 ? ir * Kp + kk : SK64_ROWS * Kp), 16)) =
+                    __builtin_bit_cast(u32x4, v[u]) & (u32x4){keep, keep, keep, keep};
+            }
+        };
+        {
+            f32x4 iv[IU];
+            img_load(0, iv);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < GC; ++i) cur[i] = loadw(g_lo + i, g_hi);
+            __builtin_amdgcn_sched_barrier(0);
+            img_store(0, iv);
+            for (int c0 = TPR * IU; c0 < kp4; c0 += TPR * IU) {   // (passes wider than 512 columns)
+                img_load(c0, iv);
+                img_store(c0, iv);
+            }
+        }
         __syncthreads();
         if (!active) continue;
         int g0 = g_lo;
@@ -399,7 +436,8 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
 // h' goes to a buffer of its own (other workgroups still read h).
 constexpr int SKG_WAVES = 12;
 constexpr int SKG_THREADS = SKG_WAVES * 64;
-constexpr int SKG_GC = 12;  // a wave's whole k range (H <= 768) is in flight at once: one memory round trip
+constexpr int SKG_GC = 12;  // 16-column groups of W per chunk, double-buffered (a 20-group single buffer -- the whole k range of
+                            // H, In <= 640 requested at once -- measured 0.8 % slower end to end)
 
 __device__ __forceinline__ float sk_sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -409,18 +447,22 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const float* __restrict__ Wih, int64_t ldi, const float* __restrict__ Whh, int64_t ldhh,
     const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo,
     int n_ub, int m_chunks) {
-    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [16 MT][Kp] = [x .. 0 | h .. 0], each padded to 16
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [16 MT][Kp] = [x .. 0 | h .. 0], each padded to 16; + 4 spare
     __shared__ __attribute__((aligned(16))) float part[SKG_WAVES][MT][64][4];
     constexpr int ROWS = 16 * MT;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // row chunks of one unit block share an XCD (see above)
     const int bx = (seq / m_chunks) * 8 + xcd, by = seq % m_chunks;
     if (bx >= n_ub) return;
+    SKG_STAMP(0);
     const int Inp = (In + 15) & ~15;
     const int m0 = by * ROWS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
     const int u0 = bx * 16;
-    const int prod = wave % 6, khalf = wave / 6;
+    // wave -> (weight block, k half): waves land on SIMD wave % 4, and the x blocks are longer than the h blocks when
+    // In > H; swapping the pairs of the second quad gives every SIMD both kinds instead of three of one
+    const int slot = wave ^ ((wave >> 2) & 1);
+    const int prod = slot % 6, khalf = slot / 6;
     const int gate = prod >> 1, panel = prod & 1;
     const int Kw = panel ? H : In, xoff = panel ? Inp : 0;
     const float* wrow = (panel ? Whh : Wih) + (int64_t)(gate * H + min(u0 + r16, H - 1)) * (panel ? ldhh : ldi) + 4 * kq;
@@ -434,16 +476,57 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
         const int k = 16 * min(g, max(g_hi, g_lo + 1) - 1);   // (wrow already carries the lane's 4 * kq)
         return *reinterpret_cast<const f32x4*>(wrow + max(min(k, Kw - 4 - 4 * kq), -4 * kq));
     };
-    f32x4 cur[SKG_GC], nxt[SKG_GC];
+    // The [x | h] image: a thread owns one row and every TPR-th 16-byte column of it (no division by a run-time
+    // value, no branch around a load: clamped addresses, masked when stored).  The image's loads are issued BEFORE
+    // the first weight chunk -- loads return in order, so the image is complete a chunk's transfer time earlier
+    // and the workgroup meets at the barrier while the weights are still arriving.
+    constexpr int TPR = SKG_THREADS / ROWS, IU = 8;
+    const int kp4 = Kp >> 2;
+    const int ir = threadIdx.x / TPR, ic = threadIdx.x % TPR;
+    const bool row_ok = m0 + ir < M;
+    const float* xrow = X + (int64_t)min(m0 + ir, M - 1) * ldx;
+    const float* hrow = Hp + (int64_t)min(m0 + ir, M - 1) * ldh;
+    auto img_load = [&](int c0, f32x4* v) {
 #pragma unroll
-    for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
-    fill_image<SKG_THREADS>(Xs, ROWS, Kp, [&](int r, int k) {
-        const int m = m0 + r;
-        if (m < M && k < In) return *reinterpret_cast<const float4*>(X + (int64_t)m * ldx + k);
-        if (m < M && k >= Inp && k - Inp < H) return *reinterpret_cast<const float4*>(Hp + (int64_t)m * ldh + (k - Inp));
-        return make_float4(0.f, 0.f, 0.f, 0.f);
-    });
+        for (int u = 0; u < IU; ++u) {
+            const int k = 4 * (c0 + ic + u * TPR);
+            v[u] = *reinterpret_cast<const f32x4*>(k < Inp ? xrow + min(k, In - 4) : hrow + min(k - Inp, H - 4));
+        }
+    };
+    auto img_store = [&](int c0, const f32x4* v) {
+#pragma unroll
+        for (int u = 0; u < IU; ++u) {
+            const int c = c0 + ic + u * TPR, k = 4 * c;
+            const bool live = row_ok && (k < Inp ? k < In : k - Inp < H);
+            // a column past the row goes to the spare 16 bytes behind the image: an unconditional store keeps the
+            // compiler from sinking its load into a branch (where it would be waited for with everything else)
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const unsigned keep = live ? 0xffffffffu : 0u;   // (masked with AND: a select on the loaded value came out as a branch)
+            *reinterpret_cast<u32x4*>(__builtin_assume_aligned(Xs + (c < kp4 ? ir * Kp + k : ROWS * Kp), 16)) =
+                __builtin_bit_cast(u32x4, v[u]) & (u32x4){keep, keep, keep, keep};
+        }
+    };
+    f32x4 cur[SKG_GC], nxt[SKG_GC];
+    {
+        f32x4 iv[IU];
+        img_load(0, iv);
+        __builtin_amdgcn_sched_barrier(0);
+        // (no memory is waited for here: the twelve waves only agree that every image load has been issued, so the
+        // image -- a third of what the CU pulls in before the first product -- is not queued behind other waves' weights)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
+        __builtin_amdgcn_sched_barrier(0);
+        img_store(0, iv);
+        for (int c0 = TPR * IU; c0 < kp4; c0 += TPR * IU) {   // (32-row images, K beyond 1536)
+            img_load(c0, iv);
+            img_store(c0, iv);
+        }
+    }
+    SKG_STAMP(1);
     __syncthreads();
+    SKG_STAMP(2);
     {
         const float* xs = Xs + r16 * Kp + xoff + 4 * kq;
         f32x4 acc[MT];
@@ -471,8 +554,9 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
             for (int i = 0; i < SKG_GC; ++i) cur[i] = nxt[i];
         }
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&part[wave][mt][lane][0]) = acc[mt];
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4*>(&part[slot][mt][lane][0]) = acc[mt];
     }
+    SKG_STAMP(3);
     // the cell's biases for the waves that apply it: all 24 loads back to back at clamped indices BEFORE the barrier
     // (one memory round trip under the wait for the other waves; guarded loads inside the per-unit branches below
     // were a round trip per unit)
@@ -488,6 +572,7 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
             }
     }
     __syncthreads();
+    SKG_STAMP(4);
     if (wave < MT) {
         // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16; k halves added low + high
         const int m = m0 + 16 * wave + r16;
@@ -509,6 +594,7 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
             }
         }
     }
+    SKG_STAMP(5);
 }
 
 int sk_cus() {
@@ -588,6 +674,9 @@ Plan64 plan64(int M, int N, int K) {
 extern "C" int dssvae_skinny_profile_read(unsigned long long* dst_host) {
     return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_skclk), sizeof(g_skclk), 0, hipMemcpyDeviceToHost);
 }
+extern "C" int dssvae_skinny_gru_profile_read(unsigned long long* dst_host) {
+    return (int)hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_skg), sizeof(g_skg), 0, hipMemcpyDeviceToHost);
+}
 #endif
 
 extern "C" int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int64_t ldw) {
@@ -635,7 +724,7 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
     if (!sk_ok(X1, ld1, K1, X2, ld2, K2, W, ldw, M)) return DSSVAE_ETOOBIG;
     const Plan64 p64 = plan64(M, N, K1 + K2);
     if (p64.use) {
-        const int lds = SK64_ROWS * p64.Kp * 4, m_chunks = (M + SK64_ROWS - 1) / SK64_ROWS;
+        const int lds = SK64_ROWS * p64.Kp * 4 + 16, m_chunks = (M + SK64_ROWS - 1) / SK64_ROWS;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_argmax64_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(skinny_argmax64_kernel, dim3(((p64.n_split + 7) / 8) * 8 * m_chunks), dim3(SK_THREADS), lds,
@@ -670,7 +759,7 @@ extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const
     hipStream_t s = (hipStream_t)stream;
 #define SKG_LAUNCH(MT)                                                                                              \
     do {                                                                                                            \
-        const int lds = 16 * MT * Kp * 4, m_chunks = (M + 16 * MT - 1) / (16 * MT);                                 \
+        const int lds = 16 * MT * Kp * 4 + 16, m_chunks = (M + 16 * MT - 1) / (16 * MT);                            \
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT>),                             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
         hipLaunchKernelGGL(skinny_gru_kernel<MT>, dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X, ldx, In,   \
@@ -680,8 +769,8 @@ extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const
     // Infinity Cache): one 16-row tile per workgroup spreads it over twice the CUs.  Two tiles per workgroup
     // (weights fetched once per 32 rows) only when that still fills the chip and the [x | h] image fits in LDS.
     const bool wide = (int64_t)grid_x * ((M + 31) / 32) >= sk_cus();
-    if (wide && 32 * Kp * 4 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
-    else if (16 * Kp * 4 + SKG_WAVES * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(1);
+    if (wide && 32 * Kp * 4 + 16 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
+    else if (16 * Kp * 4 + 16 + SKG_WAVES * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(1);
     else return DSSVAE_ETOOBIG;
 #undef SKG_LAUNCH
     DSSVAE_CHECK_LAUNCH();

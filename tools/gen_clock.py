@@ -36,3 +36,23 @@ for rep in range(3):
     ev[1].record()
     torch.cuda.synchronize()
 print("arg-max launch back to back: %.1f us" % (ev[0].elapsed_time(ev[1]) * 1e3 / 50))
+
+# the decode cell kernel: phases of workgroup 0 / wave 0 and the launch back to back
+# (layer 1 of the decoder: In = E, layer 2: In = H)
+xin, hp = torch.randn(B, H, generator=g).cuda(), torch.randn(B, H, generator=g).cuda()
+wih1 = (torch.randn(3 * H, E, generator=g) * 0.05).cuda()
+hn = torch.empty(B, H, device="cuda")
+for In, wih in ((E, wih1), (H, layers[1][0])):
+    x = xin[:, :In].contiguous()
+    for rep in range(3):
+        ev[0].record()
+        for _ in range(50):
+            L.check(lib.dssvae_skinny_gru_step(L.ptr(x), In, In, L.ptr(hp), H, H, L.ptr(wih), In, L.ptr(layers[1][1]), H,
+                                               L.ptr(layers[1][2]), L.ptr(layers[1][3]), B, L.ptr(hn), H, L.stream()), "gru_step")
+        ev[1].record()
+        torch.cuda.synchronize()
+    st = (C.c_ulonglong * 8)()
+    assert lib.dssvae_skinny_gru_profile_read(st) == 0
+    d = [(st[i + 1] - st[i]) / 100.0 for i in range(5)]
+    print("cell kernel In=%d H=%d: launch back to back %.2f us; workgroup 0: image + weight loads issued, image stored %.2f | barrier %.2f | "
+          "products %.2f | bias loads + barrier %.2f | cell + store %.2f us" % (In, H, ev[0].elapsed_time(ev[1]) * 1e3 / 50, *d))
