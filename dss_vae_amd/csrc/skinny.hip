@@ -25,34 +25,57 @@ constexpr float SK_NEG = -3.0e38f;
 // read by one 16-lane group of a ds_read_b128 fall into 16 distinct 4-bank slots (conflict-free)
 inline int padded_k(int K) { return ((K + 15) / 16) * 16 + 4; }
 
-// Build the LDS image [rows][Kp] of a workgroup's activation rows: `fetch(r, k)` answers the float4 at row r,
-// columns k..k+3 (zeros for padding).  Eight loads are in flight per thread before the first LDS store: with
-// one load per trip (load -> wait -> store) the fill is ~60 dependent L2 round trips and takes longer than
-// the weight stream it prepares.
-template <int THREADS, class F, int U = 8>
-__device__ __forceinline__ void fill_image(float* Xs, int rows, int Kp, F fetch) {
-    const int kp4 = Kp >> 2, total = rows * kp4;
-    for (int base = threadIdx.x; base < total; base += THREADS * U) {
-        float4 v[U];
+// the 32-row kernels' image + its 16 spare bytes + their static arrays (partial sums of the K split 16 KB, arg-max
+// reduction 2 KB) within the 160 KB of a CU
+inline bool sk_image_fits(int K) { return SK_ROWS * padded_k(K) * 4 + 16 + 19 * 1024 <= 160 * 1024; }
+
+// The LDS image [ROWS][Kp] of a workgroup's activation rows [X1 | X2], columns k_lo .. k_lo + kvalid of them (zeros
+// beyond, and in rows past M).  A thread owns ONE row and every TPR-th 16-byte column of it (TPR = threads / ROWS):
+// no division by a run-time value, and no branch around a load -- the addresses are clamped into the row, the values
+// masked (with AND: a select on a loaded value came out as a branch, with the load inside it) when they are stored,
+// and a column past the row goes to 16 spare bytes behind the image so that the store is unconditional and its load
+// cannot sink into a branch either.  IU loads are in flight per thread before the first store; the caller may put
+// other work between image_load and image_store.  (The fill this replaces computed row and column of every element
+// with a division and guarded every load: ~1500 instructions per thread and pass in the 64-row arg-max kernel.)
+template <int ROWS, int IU>
+struct RowImage {
+    static constexpr int TPR = SK_THREADS / ROWS;
+    const float *x1row, *x2row;
+    int K1, K, Kp, kp4, ir, ic;
+    bool row_ok;
+    __device__ __forceinline__ RowImage(const float* X1, int64_t ld1, int K1_, const float* X2, int64_t ld2, int K2,
+                                        int m0, int M, int Kp_)
+        : K1(K1_), K(K1_ + K2), Kp(Kp_), kp4(Kp_ >> 2), ir(threadIdx.x / TPR), ic(threadIdx.x % TPR) {
+        const int m = min(m0 + ir, M - 1);
+        row_ok = m0 + ir < M;
+        x1row = X1 + (int64_t)m * ld1;
+        x2row = K2 > 0 ? X2 + (int64_t)m * ld2 : x1row;
+    }
+    __device__ __forceinline__ void load(f32x4 (&v)[IU], int k_lo, int c0) const {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * THREADS;
-            v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < total) {
-                const int r = idx / kp4;
-                v[u] = fetch(r, (idx - r * kp4) << 2);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = base + u * THREADS;
-            if (idx < total) {
-                const int r = idx / kp4;
-                *reinterpret_cast<float4*>(Xs + r * Kp + ((idx - r * kp4) << 2)) = v[u];
-            }
+        for (int u = 0; u < IU; ++u) {
+            const int kc = min(k_lo + 4 * (c0 + ic + u * TPR), K - 4);
+            v[u] = *reinterpret_cast<const f32x4*>(kc < K1 ? x1row + kc : x2row + (kc - K1));
         }
     }
-}
+    __device__ __forceinline__ void store(float* Xs, const f32x4 (&v)[IU], int kvalid, int c0) const {
+#pragma unroll
+        for (int u = 0; u < IU; ++u) {
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const int c = c0 + ic + u * TPR, kk = 4 * c;
+            const unsigned keep = row_ok && kk < kvalid ? 0xffffffffu : 0u;
+            *reinterpret_cast<u32x4*>(__builtin_assume_aligned(Xs + (c < kp4 ? ir * Kp + kk : ROWS * Kp), 16)) =
+                __builtin_bit_cast(u32x4, v[u]) & (u32x4){keep, keep, keep, keep};
+        }
+    }
+    // the rest of a row wider than TPR * IU columns
+    __device__ __forceinline__ void rest(float* Xs, f32x4 (&v)[IU], int k_lo, int kvalid) const {
+        for (int c0 = TPR * IU; c0 < kp4; c0 += TPR * IU) {
+            load(v, k_lo, c0);
+            store(Xs, v, kvalid, c0);
+        }
+    }
+};
 
 // KS = waves that share one 16-column block, each taking a contiguous range of k (partials summed
 // through LDS).  The arg-max streams hundreds of blocks per workgroup (throughput-bound: KS = 1); the
@@ -64,7 +87,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp,
     int blocks_per_wg, float* __restrict__ C, int64_t ldc, int cvec, float* __restrict__ part_max,
     float* __restrict__ part_sum, int64_t* __restrict__ part_arg, int n_split, int m_chunks) {
-    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp]
+    extern __shared__ __attribute__((aligned(16))) float Xs[];  // [SK_ROWS][Kp] + 4 spare
     __shared__ float red_v[SK_WAVES][SK_ROWS];
     __shared__ int red_i[SK_WAVES][SK_ROWS];
     __shared__ __attribute__((aligned(16))) float part[KS > 1 ? SK_WAVES : 1][2][64][4];
@@ -77,12 +100,13 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_kernel(
     if (bx >= n_split) return;
     const int K = K1 + K2;
     const int m0 = by * SK_ROWS;
-    fill_image<SK_THREADS>(Xs, SK_ROWS, Kp, [&](int r, int k) {
-        const int m = m0 + r;
-        if (m >= M || k >= K) return make_float4(0.f, 0.f, 0.f, 0.f);
-        return k < K1 ? *reinterpret_cast<const float4*>(X1 + (int64_t)m * ld1 + k)
-                      : *reinterpret_cast<const float4*>(X2 + (int64_t)m * ld2 + (k - K1));
-    });
+    {
+        const RowImage<SK_ROWS, 16> img(X1, ld1, K1, X2, ld2, K2, m0, M, Kp);
+        f32x4 iv[16];
+        img.load(iv, 0, 0);
+        img.store(Xs, iv, K, 0);
+        img.rest(Xs, iv, 0, K);
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r16 = lane & 15, kq = lane >> 4;
@@ -307,53 +331,25 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
 #pragma unroll
     for (int t = 0; t < SK64_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* xs = Xs + r16 * Kp + 4 * kq;
-    constexpr int TPR = SK_THREADS / SK64_ROWS, IU = 16;
-    const int kp4 = Kp >> 2;
-    const int ir = threadIdx.x / TPR, ic = threadIdx.x % TPR;
-    const bool row_ok = m0 + ir < M;
-    const float* x1row = X1 + (int64_t)min(m0 + ir, M - 1) * ld1;
-    const float* x2row = K2 > 0 ? X2 + (int64_t)min(m0 + ir, M - 1) * ld2 : x1row;
+    const RowImage<SK64_ROWS, 16> img(X1, ld1, K1, X2, ld2, K2, m0, M, Kp);
     for (int g_lo = 0; g_lo < nG; g_lo += g_per_pass) {
         const int g_hi = min(nG, g_lo + g_per_pass);
         f32x4 cur[GC], nxt[GC];
-        // The pass's image: a thread owns one row and every TPR-th 16-byte column of it -- no division by a run-time
-        // value and no branch around a load (clamped addresses, masked when stored; a column past the row goes to
-        // the spare 16 bytes behind the image, so that the store is unconditional and its load cannot sink into a
-        // branch).  Order: image loads, then a barrier that waits for no memory (every wave has issued its image
-        // loads and is done with the previous pass's image), then the first weight chunk, in flight while the
-        // image is stored -- loads return in order, so the image is not queued behind other waves' weights.
+        // The pass's image (RowImage).  Order: image loads, then a barrier that waits for no memory (every wave has
+        // issued its image loads and is done with the previous pass's image), then the first weight chunk, in flight
+        // while the image is stored -- loads return in order, so the image is not queued behind other waves' weights.
         const int k_lo = 16 * g_lo, kvalid = min(16 * (g_hi - g_lo), K - k_lo);
-        auto img_load = [&](int c0, f32x4* v) {
-#pragma unroll
-            for (int u = 0; u < IU; ++u) {
-                const int kc = min(k_lo + 4 * (c0 + ic + u * TPR), K - 4);
-                v[u] = *reinterpret_cast<const f32x4*>(kc < K1 ? x1row + kc : x2row + (kc - K1));
-            }
-        };
-        auto img_store = [&](int c0, const f32x4* v) {
-#pragma unroll
-            for (int u = 0; u < IU; ++u) {
-                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-                const int c = c0 + ic + u * TPR, kk = 4 * c;
-                const unsigned keep = row_ok && kk < kvalid ? 0xffffffffu : 0u;
-                *reinterpret_cast<u32x4*>(__builtin_assume_aligned(Xs + (c < kp4 ? ir * Kp + kk : SK64_ROWS * Kp), 16)) =
-                    __builtin_bit_cast(u32x4, v[u]) & (u32x4){keep, keep, keep, keep};
-            }
-        };
         {
-            f32x4 iv[IU];
-            img_load(0, iv);
+            f32x4 iv[16];
+            img.load(iv, k_lo, 0);
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GC; ++i) cur[i] = loadw(g_lo + i, g_hi);
             __builtin_amdgcn_sched_barrier(0);
-            img_store(0, iv);
-            for (int c0 = TPR * IU; c0 < kp4; c0 += TPR * IU) {   // (passes wider than 512 columns)
-                img_load(c0, iv);
-                img_store(c0, iv);
-            }
+            img.store(Xs, iv, kvalid, 0);
+            img.rest(Xs, iv, k_lo, kvalid);   // (passes wider than 512 columns)
         }
         __syncthreads();
         if (!active) continue;
@@ -612,7 +608,7 @@ bool sk_ok(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, i
     if (M > DSSVAE_SKINNY_MAX_ROWS) return false;
     if ((K1 % 4) || (K2 % 4) || (ld1 % 4) || (ldw % 4) || !aligned16(X1) || !aligned16(W)) return false;
     if (K2 > 0 && ((ld2 % 4) || !aligned16(X2))) return false;
-    return SK_ROWS * padded_k(K1 + K2) * 4 <= SK_LDS_BUDGET;
+    return sk_image_fits(K1 + K2);
 }
 
 template <bool ARGMAX, int KS>
@@ -620,7 +616,7 @@ int sk_launch(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2
               int64_t ldw, const float* bias, int M, int N, int bpw, int n_wg, float* C, int64_t ldc, float* pm,
               float* ps, int64_t* pa, hipStream_t s) {
     const int Kp = padded_k(K1 + K2);
-    const int lds = SK_ROWS * Kp * 4;
+    const int lds = SK_ROWS * Kp * 4 + 16;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_kernel<ARGMAX, KS>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int cvec = C && aligned16(C) && (ldc % 4) == 0;
@@ -683,7 +679,7 @@ extern "C" int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64
     // alignment of the pointers is checked at the call; this answers for the shape
     if (M <= 0 || M > DSSVAE_SKINNY_MAX_ROWS || K1 <= 0 || K2 < 0) return 0;
     if ((K1 % 4) || (K2 % 4) || (ld1 % 4) || (ldw % 4) || (K2 > 0 && (ld2 % 4))) return 0;
-    return SK_ROWS * padded_k(K1 + K2) * 4 <= SK_LDS_BUDGET;
+    return sk_image_fits(K1 + K2);
 }
 
 extern "C" int dssvae_skinny_argmax_splits(int M, int N) {
