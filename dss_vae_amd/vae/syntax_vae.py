@@ -120,8 +120,10 @@ class TwoEncoderVAE(BaseVAE):
         B = hid.size(0)
         halves = hid.contiguous().view(B, 2, -1)
         sem_h, syn_h = halves[:, 0, :], halves[:, 1, :]
-        ret["syn_mean"], ret["syn_logv"] = self.syn_mean(syn_h), self.syn_logv(syn_h)
-        ret["sem_mean"], ret["sem_logv"] = self.sem_mean(sem_h), self.sem_logv(sem_h)
+        # four [B, var_dim] x [var_dim, Z] products: one grouped launch (alone each is a chain of k-tiles on 4 CUs)
+        ret["syn_mean"], ret["syn_logv"], ret["sem_mean"], ret["sem_logv"] = ops.linear_many(
+            [(x, m.weight, m.bias) for x, m in ((syn_h, self.syn_mean), (syn_h, self.syn_logv),
+                                                (sem_h, self.sem_mean), (sem_h, self.sem_logv))])
         e_syn = self._randn("eps_syn", [B, self.latent_size]) if is_sampling else None  # syntax eps first
         e_sem = self._randn("eps_sem", [B, self.latent_size]) if is_sampling else None
         ret["syn_z"], ret["syn_kl"] = ops.reparam_kl(ret["syn_mean"], ret["syn_logv"], e_syn)
@@ -138,8 +140,9 @@ class TwoEncoderVAE(BaseVAE):
         def lay(x):
             return x.view(B, self.enc_hidden_factor, int(self.enc_hidden_dim / 2)).permute(1, 0, 2)
 
-        ret["syn_hidden"] = lay(self.syn_to_h(ret["syn_z"]))
-        ret["sem_hidden"] = lay(self.sem_to_h(ret["sem_z"]))
+        syn_h, sem_h = ops.linear_many([(ret["syn_z"], self.syn_to_h.weight, self.syn_to_h.bias),
+                                        (ret["sem_z"], self.sem_to_h.weight, self.sem_to_h.bias)])
+        ret["syn_hidden"], ret["sem_hidden"] = lay(syn_h), lay(sem_h)
         ret["decode_init"] = torch.cat([ret["syn_hidden"], ret["sem_hidden"]], dim=-1)
         return ret
 
