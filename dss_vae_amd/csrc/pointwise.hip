@@ -276,6 +276,47 @@ inline unsigned grid_for(int64_t n, int block = 256, int cap = 2048) {
 
 }  // namespace
 
+// Scalar loss assembly (vae/enhance_syntax_vae.py:212-340 in the reference: ~40 one-element torch ops forward and
+// ~25 backward): out[j] = sum_k coef[j][k] * sum(in[k]).  One workgroup: wave w sums input w, w + 16, ... in a fixed
+// order (lane-strided partials, then the wave's shuffle tree), the sums meet in LDS, thread j forms out[j].
+struct WSums {
+    const float* in[DSSVAE_WSUMS_MAX];
+    float* din[DSSVAE_WSUMS_MAX];
+    const float* dout[DSSVAE_WSUMS_MAX];
+    int len[DSSVAE_WSUMS_MAX];
+    float coef[DSSVAE_WSUMS_MAX][DSSVAE_WSUMS_MAX];   // [out][in]
+    int n_in, n_out;
+};
+
+__global__ __launch_bounds__(1024) void weighted_sums_fwd_kernel(WSums a, float* __restrict__ out) {
+    __shared__ float comp[DSSVAE_WSUMS_MAX];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int k = wave; k < a.n_in; k += 16) {
+        float s = 0.f;
+        for (int i = lane; i < a.len[k]; i += 64) s += a.in[k][i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+        if (lane == 0) comp[k] = s;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_out) {
+        float v = 0.f;
+        for (int k = 0; k < a.n_in; ++k) v += a.coef[threadIdx.x][k] * comp[k];
+        out[threadIdx.x] = v;
+    }
+}
+
+// backward: din[k][i] = sum_j *dout[j] * coef[j][k] for every element of every input that wants a gradient (an output
+// without a gradient has dout[j] = NULL)
+__global__ __launch_bounds__(256) void weighted_sums_bwd_kernel(WSums a) {
+    const int k = blockIdx.y;
+    if (!a.din[k]) return;
+    float g = 0.f;
+    for (int j = 0; j < a.n_out; ++j)
+        if (a.dout[j]) g += a.dout[j][0] * a.coef[j][k];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.len[k]; i += gridDim.x * 256) a.din[k][i] = g;
+}
+
 extern "C" int dssvae_abi_version(void) { return DSSVAE_ABI_VERSION; }
 
 extern "C" int dssvae_device_cus(int* n) {
@@ -436,6 +477,51 @@ extern "C" int dssvae_adam_step(float* p, const float* g, float* m, float* v, in
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                        beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask, skip_flag);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+static int wsums_pack(WSums* a, const float* const* in, float* const* din, const int32_t* len, int n_in,
+                      const float* coef, int n_out) {
+    if (!len || !coef || n_in <= 0 || n_out <= 0) return DSSVAE_EINVAL;
+    if (n_in > DSSVAE_WSUMS_MAX || n_out > DSSVAE_WSUMS_MAX) return DSSVAE_ETOOBIG;
+    a->n_in = n_in;
+    a->n_out = n_out;
+    for (int k = 0; k < n_in; ++k) {
+        if (len[k] < 0 || (in && len[k] > 0 && !in[k])) return DSSVAE_EINVAL;
+        a->in[k] = in ? in[k] : nullptr;
+        a->din[k] = din ? din[k] : nullptr;
+        a->len[k] = len[k];
+    }
+    for (int j = 0; j < n_out; ++j)
+        for (int k = 0; k < n_in; ++k) a->coef[j][k] = coef[j * n_in + k];
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_weighted_sums_fwd(const float* const* in, const int32_t* len, int n_in, const float* coef,
+                                        int n_out, float* out, void* stream) {
+    if (!in || !out) return DSSVAE_EINVAL;
+    WSums a = {};
+    const int e = wsums_pack(&a, in, nullptr, len, n_in, coef, n_out);
+    if (e != DSSVAE_OK) return e;
+    hipLaunchKernelGGL(weighted_sums_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, out);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_weighted_sums_bwd(float* const* din, const int32_t* len, int n_in, const float* coef, int n_out,
+                                        const float* const* dout, void* stream) {
+    if (!din || !dout) return DSSVAE_EINVAL;
+    WSums a = {};
+    const int e = wsums_pack(&a, nullptr, din, len, n_in, coef, n_out);
+    if (e != DSSVAE_OK) return e;
+    for (int j = 0; j < n_out; ++j) a.dout[j] = dout[j];
+    int longest = 0;
+    for (int k = 0; k < n_in; ++k)
+        if (din[k]) longest = len[k] > longest ? len[k] : longest;
+    if (longest == 0) return DSSVAE_OK;
+    const int bx = (longest + 255) / 256;
+    hipLaunchKernelGGL(weighted_sums_bwd_kernel, dim3(bx > 64 ? 64 : bx, n_in), dim3(256), 0, (hipStream_t)stream, a);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

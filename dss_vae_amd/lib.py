@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 5  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 6  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -88,6 +88,8 @@ _SIGNATURES = {
     "dssvae_unk_replace": ([_P, _L, _P, _F, _U64, _L, _L, _L, _L, _P, _P], _I),
     "dssvae_reparam_kl_fwd": ([_P, _P, _P, _L, _P, _P, _P], _I),
     "dssvae_reparam_kl_bwd": ([_P, _P, _P, _P, _P, _L, _P, _P, _P], _I),
+    "dssvae_weighted_sums_fwd": ([C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I, C.POINTER(C.c_float), _I, _P, _P], _I),
+    "dssvae_weighted_sums_bwd": ([C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I, C.POINTER(C.c_float), _I, C.POINTER(C.c_void_p), _P], _I),
     "dssvae_gru_workspace_bytes": ([_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)], _L),
     "dssvae_gru_resident_workgroups": ([_I, _I, _I, C.POINTER(C.c_int)], _I),
     "dssvae_gru_layout": ([_I, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), _I, _I,

@@ -457,6 +457,56 @@ class _ReparamKLFn(Function):
         return dm, dv, None
 
 
+class _WeightedSumsFn(Function):
+    """out_j = sum_k coef[j][k] * sum(x_k): the scalar loss assembly in one launch (and one for its backward).  The
+    outputs are separate 0-d views of one buffer, so backward gets one gradient per output (None for the reported-only
+    ones) and hands their addresses to the kernel: no stacking, no select-backward zero fills."""
+
+    @staticmethod
+    def forward(ctx, coef, *xs):
+        ctx.set_materialize_grads(False)
+        L.require_cuda(*xs)
+        flat = [_f32(x).reshape(-1).contiguous() for x in xs]
+        n_in, n_out = len(flat), len(coef)
+        out = torch.empty(n_out, device=flat[0].device, dtype=torch.float32)
+        ptrs = (C.c_void_p * n_in)(*[x.data_ptr() for x in flat])
+        lens = (C.c_int32 * n_in)(*[x.numel() for x in flat])
+        cf = (C.c_float * (n_in * n_out))(*[float(c) for row in coef for c in row])
+        L.check(L.load().dssvae_weighted_sums_fwd(ptrs, lens, n_in, cf, n_out, L.ptr(out), L.stream()),
+                "dssvae_weighted_sums_fwd")
+        ctx.coef, ctx.cf, ctx.lens = coef, cf, lens
+        ctx.shapes = [x.shape for x in xs]
+        ctx.dev = out.device
+        return tuple(out[j] for j in range(n_out))
+
+    @staticmethod
+    def backward(ctx, *douts):
+        n_in, n_out = len(ctx.shapes), len(ctx.coef)
+        live_out = [j for j in range(n_out) if douts[j] is not None]
+        # an input none of whose live outputs carries a non-zero coefficient gets NO gradient (None, not zeros):
+        # the optimiser's "no gradient = parameter skipped" semantics depend on it (adversary terms before warm_up)
+        want = [ctx.needs_input_grad[1 + k] and any(ctx.coef[j][k] != 0.0 for j in live_out) for k in range(n_in)]
+        if not any(want):
+            return (None,) * (1 + n_in)
+        sizes = [ctx.lens[k] if want[k] else 0 for k in range(n_in)]
+        buf = torch.empty(sum(sizes), device=ctx.dev, dtype=torch.float32)
+        grads, off = [], 0
+        for k in range(n_in):
+            grads.append(buf[off:off + sizes[k]].view(ctx.shapes[k]) if want[k] else None)
+            off += sizes[k]
+        g = [None if d is None else _f32(d).contiguous() for d in douts]
+        dptr = (C.c_void_p * n_out)(*[None if d is None else d.data_ptr() for d in g])
+        iptr = (C.c_void_p * n_in)(*[None if x is None else x.data_ptr() for x in grads])
+        L.check(L.load().dssvae_weighted_sums_bwd(iptr, ctx.lens, n_in, ctx.cf, n_out, dptr, L.stream()),
+                "dssvae_weighted_sums_bwd")
+        return (None, *grads)
+
+
+def weighted_sums(coef, xs):
+    """coef[j][k] (python floats), xs[k] (tensors of any shape) -> tuple of 0-d tensors out_j = sum_k coef[j][k] * xs[k].sum()"""
+    return _WeightedSumsFn.apply(tuple(tuple(float(c) for c in row) for row in coef), *xs)
+
+
 def reparam_kl(mean, logv, eps):
     """-> (z, kl_sum); eps None => z = mean."""
     return _ReparamKLFn.apply(mean, logv, eps)

@@ -4,6 +4,7 @@ detach()/reload(), :573-579) so gradient reaches the latents but not the adversa
 enters 'Loss' only when train_iter > warm_up (:333)."""
 import torch
 
+from .. import ops
 from ..decoder.rnn_decoder import prepare_job, score_many
 from ..utils.nn_funcs import wd_anneal_function
 from .syntax_vae import BridgeMLP, BridgeRNN, TwoEncoderVAE
@@ -29,6 +30,40 @@ def _finish(job, logp):
     if job.get("norm_by_word_len"):
         logp = logp.div(job["targets"].ne(job["dec"].pad_id).sum(-1).float() + 1e-9)
     return logp
+
+
+class _Row(dict):
+    """a linear combination {component index: coefficient} of the assembly's component sums"""
+
+    def __add__(self, other):
+        out = _Row(self)
+        for k, c in other.items():
+            out[k] = out.get(k, 0.0) + c
+        return out
+
+    def __mul__(self, c):
+        return _Row({k: v * c for k, v in self.items()})
+
+
+class _Assembly:
+    """The loss dictionary as rows of coefficients over the sums of a few tensors (per-sentence log-likelihoods,
+    bag-of-words losses, KL terms); `run` evaluates every row in one launch (ops.weighted_sums)."""
+
+    def __init__(self):
+        self.parts, self.rows = [], {}
+
+    def term(self, signed, weight):
+        """weight * sign * sum(tensor) as a row; `signed` = (sign, tensor), or None for a head that is switched off"""
+        if signed is None:
+            return _Row()
+        self.parts.append(signed[1])
+        return _Row({len(self.parts) - 1: signed[0] * weight})
+
+    def run(self, rows=None):
+        rows = self.rows if rows is None else rows
+        names = list(rows)
+        vals = ops.weighted_sums([[rows[n].get(k, 0.0) for k in range(len(self.parts))] for n in names], self.parts)
+        return dict(zip(names, vals))
 
 
 class MLPPredictor(BridgeMLP):
@@ -75,15 +110,22 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
             jobs.append(self.syn_to_sent.job(syn_h, sem_tgt)); names.append("syn_to_sent")
         return jobs, names
 
-    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=()):
+    def _dis_terms(self, syn_h, sem_h, syn_tgt, sem_tgt, extra_jobs=(), raw=False):
         """adversary terms; `extra_jobs` (already prepared main-head jobs) ride in the same persistent
-        GRU launches, their log-probs are returned second."""
+        GRU launches, their log-probs are returned second.  raw: the terms stay (sign, per-sentence vector) pairs
+        -- None for a head that is switched off -- for the fused loss assembly (`_Assembly`)."""
         a = self.args
         jobs, names = self._adv_jobs(syn_h, sem_h, syn_tgt, sem_tgt)
         for j in jobs:
             prepare_job(j)
         res = score_many(list(extra_jobs) + jobs) if (jobs or extra_jobs) else []
         ne = len(extra_jobs)
+        if raw:
+            d = {"sem_to_syn": None, "sem_to_sent": None, "syn_to_sent": None,
+                 "syn_to_sem": (1.0, self.syn_to_sem.per_sentence(syn_h, sem_tgt)) if a.syn_to_sem > 0.0 else None}
+            for n, r in zip(names, res[ne:]):
+                d[n] = (-1.0, r)
+            return d, res[:ne]
         d = {"sem_to_syn": 0.0, "sem_to_sent": 0.0, "syn_to_sent": 0.0,
              "syn_to_sem": self.syn_to_sem.forward(hidden=syn_h, tgt_var=sem_tgt) if a.syn_to_sem > 0.0 else 0.0}
         for n, r in zip(names, res[ne:]):
@@ -124,7 +166,7 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
         sem_loss = self.mul_sem.forward(hidden=semantic_hidden, tgt_var=sem_tgt)
         return self.args.mul_syn * syn_loss, self.args.mul_sem * sem_loss
 
-    def forward(self, examples, is_dis=False, norm_by_word=False):
+    def forward(self, examples, is_dis=False, norm_by_word=False, defer_assembly=False):
         batch, ret = self._front(examples)
         tgt_var, syn_var = batch.tgt_var, batch.syn_var
         syn_h, sem_h = ret["syn_hidden"], ret["sem_hidden"]
@@ -144,37 +186,50 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
         # shared src/tgt embeddings, a reference quirk pinned by the golden 'nograd' lists), then the
         # adversaries read theirs.  The recurrences of all five sequence heads then share launches.
         main_jobs = [prepare_job(self._main_job(ret, tgt_var)), prepare_job(self.mul_syn.job(syn_h, syn_var))]
-        mul_sem_loss = a.mul_sem * self.mul_sem.forward(hidden=sem_h, tgt_var=tgt_var)
+        bow = self.mul_sem.per_sentence(sem_h, tgt_var)
         if self.training:
             for n in self.ADVERSARIES:
                 getattr(self, n).detach()
-        d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs)
-        if a.infer_weight > 0.0:
-            adv_for_syn = a.syn_to_sem * d["syn_to_sem"] + a.infer_weight * a.syn_to_sent * d["syn_to_sent"]
-            adv_for_sem = a.sem_to_syn * d["sem_to_syn"] + a.infer_weight * a.sem_to_sent * d["sem_to_sent"]
+        d, (rec, tree) = self._dis_terms(syn_h, sem_h, syn_var, tgt_var, extra_jobs=main_jobs, raw=True)
+        # Everything from here to the loss dictionary is linear in the sums of these vectors: ONE launch forms all of
+        # it (ops.weighted_sums) instead of ~40 one-element torch ops forward and ~25 backward.
+        asm = _Assembly()
+        iw = a.infer_weight
+        adv = asm.term(d["syn_to_sem"], a.syn_to_sem) + asm.term(d["sem_to_syn"], a.sem_to_syn)
+        if iw > 0.0:
+            adv = adv + asm.term(d["syn_to_sent"], iw * a.syn_to_sent) + asm.term(d["sem_to_sent"], iw * a.sem_to_sent)
+        syn_loss = asm.term((-1.0, tree), a.mul_syn)
+        sem_loss = asm.term((1.0, bow), a.mul_sem)
+        asm.rows.update({"adv": adv, "mul": syn_loss + sem_loss, "nll_loss": asm.term((-1.0, rec), 1.0),
+                         "sem_loss": sem_loss, "syn_loss": syn_loss})
+        ret["batch_size"] = len(batch)
+        if defer_assembly:
+            ret["assembly"] = asm
         else:
-            adv_for_syn, adv_for_sem = a.syn_to_sem * d["syn_to_sem"], a.sem_to_syn * d["sem_to_syn"]
-        mul_syn_loss = a.mul_syn * (-tree).sum()
-        ret["adv"], ret["mul"] = adv_for_syn + adv_for_sem, mul_syn_loss + mul_sem_loss
-        ret["nll_loss"] = (-rec).sum()
-        ret["sem_loss"], ret["syn_loss"], ret["batch_size"] = mul_sem_loss, mul_syn_loss, len(batch)
+            ret.update(asm.run())
         return ret
 
     def get_loss(self, examples, train_iter, is_dis=False, **kwargs):
         a = self.args
         self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, train_iter, a.k, a.x0)
-        explore = self.forward(examples, is_dis, norm_by_word=False)
+        explore = self.forward(examples, is_dis, norm_by_word=False, defer_assembly=True)
         if is_dis:
             return explore
-        sem_kl, syn_kl, kl_loss, kl_weight = self._kl_terms(explore, train_iter)
-        B = explore["batch_size"]
-        kl_loss = kl_loss / B
-        mul_loss, adv_loss, nll_loss = explore["mul"] / B, explore["adv"] / B, explore["nll_loss"] / B
+        asm, B = explore["assembly"], float(explore["batch_size"])
+        kl_weight = self.get_kl_weight(train_iter) * a.kl_factor
+        sem_kl, syn_kl = asm.term((1.0, explore["sem_kl"]), 1.0), asm.term((1.0, explore["syn_kl"]), 1.0)
+        r = asm.rows
+        kl_loss = (sem_kl * a.sem_weight + syn_kl * a.syn_weight) * (1.0 / (a.sem_weight + a.syn_weight)) * (1.0 / B)
+        mul_loss, adv_loss, nll_loss = r["mul"] * (1.0 / B), r["adv"] * (1.0 / B), r["nll_loss"] * (1.0 / B)
         kl_item = kl_loss * kl_weight
-        loss = kl_item + nll_loss + mul_loss - adv_loss if train_iter > a.warm_up else kl_item + nll_loss + mul_loss
-        return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
-                "KL Weight": kl_weight, "KL Item": kl_item, "Model Score": kl_loss + nll_loss,
-                "ELBO": kl_item + nll_loss, "Loss": loss, "SYN KL Loss": syn_kl / B, "SEM KL Loss": sem_kl / B}
+        loss = kl_item + nll_loss + mul_loss
+        if train_iter > a.warm_up:
+            loss = loss + adv_loss * -1.0
+        out = asm.run({"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
+                       "KL Item": kl_item, "Model Score": kl_loss + nll_loss, "ELBO": kl_item + nll_loss, "Loss": loss,
+                       "SYN KL Loss": syn_kl * (1.0 / B), "SEM KL Loss": sem_kl * (1.0 / B)})
+        out["KL Weight"] = kl_weight
+        return out
 
     def eval_syntax(self, examples):
         ret = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(examples, need_sort=True), False))

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 5 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout */
+#define DSSVAE_ABI_VERSION 6 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -195,6 +195,22 @@ int dssvae_reparam_kl_fwd(const float* mean, const float* logv, const float* eps
                           float* z, float* kl_out, void* stream);
 int dssvae_reparam_kl_bwd(const float* mean, const float* logv, const float* eps, const float* dz,
                           const float* dkl, int64_t n, float* dmean, float* dlogv, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Scalar loss assembly: out[j] = sum_k coef[j*n_in + k] * sum(in[k][0 .. len[k])), j < n_out.
+ * Replaces the one-element torch ops between the heads' per-sentence log-likelihoods / KL terms and
+ * the loss dictionary (vae/enhance_syntax_vae.py:212-288 forward: the adv / mul / nll sums and their
+ * weights; :290-340 get_loss: division by the batch size, KL weight, 'Loss', 'ELBO', 'Model Score').
+ * `in`, `len`, `coef` are HOST arrays (n_in device pointers, their element counts, the row-major
+ * n_out x n_in coefficients); n_in, n_out <= DSSVAE_WSUMS_MAX.  Sums run in a fixed order.
+ * Backward: din[k][i] = sum_j *dout[j] * coef[j*n_in + k] for every k with din[k] != NULL; dout is a
+ * HOST array of n_out device pointers to one float each, NULL for an output without a gradient.
+ * ------------------------------------------------------------------------------------------- */
+#define DSSVAE_WSUMS_MAX 16
+int dssvae_weighted_sums_fwd(const float* const* in, const int32_t* len, int n_in, const float* coef, int n_out,
+                             float* out, void* stream);
+int dssvae_weighted_sums_bwd(float* const* din, const int32_t* len, int n_in, const float* coef, int n_out,
+                             const float* const* dout, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Persistent GRU recurrence (recurrent half of nn.GRU; encoder/rnn_encoder.py:52,

@@ -536,6 +536,28 @@ def test_skinny_gru_step(M, In, H):
                                       2048, L.ptr(d[4]), L.ptr(d[5]), M, L.ptr(out), 2048, L.stream()) == -2
 
 
+def test_weighted_sums_loss_assembly():
+    """out_j = sum_k coef[j][k] * sum(x_k) against fp64; gradients broadcast per input; an input whose live outputs
+    all carry a zero coefficient gets None (not zeros); an output that received no gradient contributes nothing"""
+    from dss_vae_amd import ops
+    xs = [rnd(256, seed=1), rnd(1, seed=2).reshape(()), rnd(1000, seed=3), rnd(7, 3, seed=4), rnd(1, seed=5)]
+    coef = [[1.0, 0.5, 0.0, -2.0, 0.0], [0.0, 0.0, 0.25, 0.0, 0.0], [-1.0 / 256, 3.0, 0.0, 0.0, 0.0]]
+    xd = [x.to(DEV).requires_grad_(True) for x in xs]
+    outs = ops.weighted_sums(coef, xd)
+    sums = torch.stack([x.double().sum() for x in xs])
+    ref = torch.tensor(coef, dtype=torch.float64) @ sums
+    close(torch.stack(list(outs)), ref, what="weighted sums")
+    assert all(o.dim() == 0 for o in outs)
+    (outs[0] * 2.0 + outs[2]).backward()      # outs[1] (the only row that reads x_2) stays without a gradient
+    g = [2.0 * coef[0][k] + coef[2][k] for k in range(5)]
+    for k in (0, 1, 3):
+        close(xd[k].grad, torch.full(xs[k].shape, g[k], dtype=torch.float64), what="grad %d" % k)
+    assert xd[2].grad is None and xd[4].grad is None
+    # the C-ABI's limits
+    with pytest.raises(RuntimeError):
+        ops.weighted_sums([[1.0] * 17], [x.to(DEV) for x in [rnd(3, seed=i) for i in range(17)]])
+
+
 def test_sumsq_and_adam():
     from dss_vae_amd import ops
     n = 100003
