@@ -162,16 +162,37 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     int cur[DSSVAE_DECODE_MAX_LAYERS] = {0, 0, 0, 0};  // which half of the ping-pong holds layer l's state
 #define TRY(call) do { rc = (call); if (rc != DSSVAE_OK) return rc; } while (0)
     TRY(dssvae_embed_gather(p->embedding, p->ld_embedding, w.tok, B, E, nullptr, w.x, E, stream));
+    // The tokens of step t are picked from the arg-max partials by the FIRST cell launch of step t + 1 (which reads
+    // their embedding rows straight into its image and leaves tokens and rows behind for the projection), so a step
+    // is n_layers + 1 launches; only the last step -- or a cell outside the fused kernel's range -- takes the
+    // separate pick-and-gather launch.
+    bool pending = false;  // the previous step's partials have not been turned into tokens + rows yet
+    int S_prev = 0;
+    auto pick_alone = [&](int t_of) {
+        hipLaunchKernelGGL(combine_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pmax, w.parg, B, S_prev,
+                           tokens + (size_t)t_of * B, p->embedding, p->ld_embedding, E, w.x);
+    };
     for (int t = 0; t < max_len; ++t) {
-        // x holds the embedding rows of the previous tokens: the kernel that picks the tokens of a step also
-        // fetches their rows (no per-step copy or gather launch: at ~4.5 us each they cost as much as a cell)
         const float* in = w.x;
         int in_dim = E;
         for (int l = 0; l < L; ++l) {
             float* hl = w.h + ((size_t)cur[l] * L + l) * B * H;
             float* hn = w.h + ((size_t)(cur[l] ^ 1) * L + l) * B * H;
-            rc = dssvae_skinny_gru_step(in, in_dim, in_dim, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l], H, p->b_ih[l],
-                                        p->b_hh[l], B, hn, H, stream);
+            rc = DSSVAE_ETOOBIG;
+            if (l == 0 && pending) {
+                rc = dssvae_skinny_gru_step_pick(w.pmax, w.parg, S_prev, tokens + (size_t)(t - 1) * B, p->embedding,
+                                                 p->ld_embedding, E, w.x, E, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l],
+                                                 H, p->b_ih[l], p->b_hh[l], B, hn, H, stream);
+                if (rc != DSSVAE_OK && rc != DSSVAE_ETOOBIG) return rc;
+                if (rc == DSSVAE_ETOOBIG) {
+                    pick_alone(t - 1);
+                    DSSVAE_CHECK_LAUNCH();
+                }
+                pending = false;
+            }
+            if (rc == DSSVAE_ETOOBIG)
+                rc = dssvae_skinny_gru_step(in, in_dim, in_dim, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l], H,
+                                            p->b_ih[l], p->b_hh[l], B, hn, H, stream);
             if (rc == DSSVAE_OK) {
                 cur[l] ^= 1;
                 hl = hn;
@@ -196,8 +217,11 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
         }
         prof_mark(s);
         if (rc != DSSVAE_OK) return rc;
-        hipLaunchKernelGGL(combine_gather_kernel, dim3((B + 3) / 4), dim3(256), 0, s, w.pmax, w.parg, B, S,
-                           tokens + (size_t)t * B, p->embedding, p->ld_embedding, E, w.x);
+        pending = true;
+        S_prev = S;
+    }
+    if (pending) {
+        pick_alone(max_len - 1);
         DSSVAE_CHECK_LAUNCH();
     }
 #undef TRY

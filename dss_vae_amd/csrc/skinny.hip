@@ -437,14 +437,30 @@ constexpr int SKG_GC = 12;  // 16-column groups of W per chunk, double-buffered 
 
 __device__ __forceinline__ float sk_sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
-template <int MT>
+// PICK: the step's input rows are not in X yet -- the previous step's arg-max left its per-split partials, and this
+// launch first picks every sentence's token from them (what combine_gather_kernel does: best of the S splits, ties to
+// the smaller split), reads the token's embedding row straight into the image, and the workgroups of unit block 0
+// write tokens and rows out for the projection that follows.  One launch (4 us + the gap in front of it) less per step.
+struct SkgPick {
+    const float* pm;       // [M][S] split maxima
+    const int64_t* pa;     // [M][S] their columns
+    int S;
+    int64_t* tok_out;      // [M]
+    const float* table;    // embedding rows
+    int64_t ldt;
+    float* xout;           // [M][In] the picked rows, for the projection's second panel
+    int64_t ldxo;
+};
+
+template <int MT, bool PICK>
 __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const float* __restrict__ X, int64_t ldx, int In, const float* __restrict__ Hp, int64_t ldh, int H,
     const float* __restrict__ Wih, int64_t ldi, const float* __restrict__ Whh, int64_t ldhh,
     const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo,
-    int n_ub, int m_chunks) {
+    int n_ub, int m_chunks, SkgPick pk) {
     extern __shared__ __attribute__((aligned(16))) float Xs[];  // [16 MT][Kp] = [x .. 0 | h .. 0], each padded to 16; + 4 spare
     __shared__ __attribute__((aligned(16))) float part[SKG_WAVES][MT][64][4];
+    __shared__ int tok_s[16 * MT];
     constexpr int ROWS = 16 * MT;
     const int xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;  // row chunks of one unit block share an XCD (see above)
     const int bx = (seq / m_chunks) * 8 + xcd, by = seq % m_chunks;
@@ -480,8 +496,55 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const int kp4 = Kp >> 2;
     const int ir = threadIdx.x / TPR, ic = threadIdx.x % TPR;
     const bool row_ok = m0 + ir < M;
-    const float* xrow = X + (int64_t)min(m0 + ir, M - 1) * ldx;
     const float* hrow = Hp + (int64_t)min(m0 + ir, M - 1) * ldh;
+    f32x4 cur[SKG_GC], nxt[SKG_GC];
+    if (PICK) {
+        // wave w picks the tokens of rows w, w + 12, ...: every lane takes every 64th split (value and column in one
+        // batch of loads, clamped and masked), then the wave's shuffle tree.  The first weight chunk is requested
+        // behind these loads and arrives while the tokens are picked.
+        constexpr int PJ = 4;
+        for (int r = wave; r < ROWS; r += SKG_WAVES) {
+            const int m = min(m0 + r, M - 1);
+            const float* rm = pk.pm + (int64_t)m * pk.S;
+            const int64_t* ra = pk.pa + (int64_t)m * pk.S;
+            float mx = -3.0e38f;
+            int best = 0x7fffffff, arg = 0;
+            for (int s0 = 0; s0 < pk.S; s0 += 64 * PJ) {
+                float v[PJ];
+                int64_t a[PJ];
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+                    const int sc = min(s0 + lane + 64 * j, pk.S - 1);
+                    v[j] = rm[sc];
+                    a[j] = ra[sc];
+                }
+                if (r == wave && s0 == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int j = 0; j < PJ; ++j) {
+                    const int sj = s0 + lane + 64 * j;
+                    if (sj < pk.S && v[j] > mx) { mx = v[j]; best = sj; arg = (int)a[j]; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float m2 = __shfl_xor(mx, o, 64);
+                const int b2 = __shfl_xor(best, o, 64), a2 = __shfl_xor(arg, o, 64);
+                if (m2 > mx || (m2 == mx && b2 < best)) { mx = m2; best = b2; arg = a2; }
+            }
+            if (best == 0x7fffffff) arg = (int)ra[0];   // (no split above the floor: the first, as combine_gather_kernel)
+            if (lane == 0) {
+                tok_s[r] = arg;
+                if (bx == 0 && m0 + r < M) pk.tok_out[m0 + r] = arg;
+            }
+        }
+        __syncthreads();
+    }
+    const float* xrow = PICK ? pk.table + (int64_t)tok_s[PICK ? ir : 0] * pk.ldt : X + (int64_t)min(m0 + ir, M - 1) * ldx;
     auto img_load = [&](int c0, f32x4* v) {
 #pragma unroll
         for (int u = 0; u < IU; ++u) {
@@ -500,20 +563,24 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
             const unsigned keep = live ? 0xffffffffu : 0u;   // (masked with AND: a select on the loaded value came out as a branch)
             *reinterpret_cast<u32x4*>(__builtin_assume_aligned(Xs + (c < kp4 ? ir * Kp + k : ROWS * Kp), 16)) =
                 __builtin_bit_cast(u32x4, v[u]) & (u32x4){keep, keep, keep, keep};
+            if (PICK && bx == 0 && row_ok && k < In)
+                *reinterpret_cast<f32x4*>(pk.xout + (int64_t)(m0 + ir) * pk.ldxo + k) = v[u];
         }
     };
-    f32x4 cur[SKG_GC], nxt[SKG_GC];
     {
         f32x4 iv[IU];
         img_load(0, iv);
-        __builtin_amdgcn_sched_barrier(0);
-        // (no memory is waited for here: the twelve waves only agree that every image load has been issued, so the
-        // image -- a third of what the CU pulls in before the first product -- is not queued behind other waves' weights)
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
+        if (!PICK) {
+            __builtin_amdgcn_sched_barrier(0);
+            // (no memory is waited for here: the twelve waves only agree that every image load has been issued, so
+            // the image -- a third of what the CU pulls in before the first product -- is not queued behind other
+            // waves' weights)
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
-        __builtin_amdgcn_sched_barrier(0);
+            for (int i = 0; i < SKG_GC; ++i) cur[i] = loadw(g_lo + i);
+            __builtin_amdgcn_sched_barrier(0);
+        }
         img_store(0, iv);
         for (int c0 = TPR * IU; c0 < kp4; c0 += TPR * IU) {   // (32-row images, K beyond 1536)
             img_load(c0, iv);
@@ -740,35 +807,76 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
                            part_max, part_sum, part_arg, (hipStream_t)stream);
 }
 
-extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H,
-                                      const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
-                                      const float* bih, const float* bhh, int M, float* Hnew, int64_t ldo,
-                                      void* stream) {
-    if (!X || !Hprev || !Wih || !Whh || !bih || !bhh || !Hnew || M <= 0 || In <= 0 || H <= 0 || ldx < In || ldh < H ||
-        ldi < In || ldhh < H || ldo < H || Hnew == Hprev)
-        return DSSVAE_EINVAL;
-    if (M > DSSVAE_SKINNY_MAX_ROWS || (In % 4) || (H % 4) || (ldx % 4) || (ldh % 4) || (ldi % 4) || (ldhh % 4) ||
-        !aligned16(X) || !aligned16(Hprev) || !aligned16(Wih) || !aligned16(Whh))
-        return DSSVAE_ETOOBIG;
+namespace {
+int skg_launch(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H, const float* Wih,
+               int64_t ldi, const float* Whh, int64_t ldhh, const float* bih, const float* bhh, int M, float* Hnew,
+               int64_t ldo, const SkgPick* pick, hipStream_t s) {
     const int Kp = ((In + 15) & ~15) + padded_k(H);
     const int n_ub = (H + 15) / 16, grid_x = ((n_ub + 7) / 8) * 8;
-    hipStream_t s = (hipStream_t)stream;
-#define SKG_LAUNCH(MT)                                                                                              \
+    const SkgPick pk = pick ? *pick : SkgPick{};
+#define SKG_LAUNCH(MT, PICK)                                                                                        \
     do {                                                                                                            \
         const int lds = 16 * MT * Kp * 4 + 16, m_chunks = (M + 16 * MT - 1) / (16 * MT);                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT>),                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT, PICK>),                       \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
-        hipLaunchKernelGGL(skinny_gru_kernel<MT>, dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X, ldx, In,   \
-                           Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub, m_chunks);         \
+        hipLaunchKernelGGL((skinny_gru_kernel<MT, PICK>), dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X,    \
+                           ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub, m_chunks, \
+                           pk);                                                                                     \
     } while (0)
     // The step is bound by the fp32 MFMA rate of the CUs it occupies, not by the weight stream (a few MB from the
     // Infinity Cache): one 16-row tile per workgroup spreads it over twice the CUs.  Two tiles per workgroup
     // (weights fetched once per 32 rows) only when that still fills the chip and the [x | h] image fits in LDS.
     const bool wide = (int64_t)grid_x * ((M + 31) / 32) >= sk_cus();
-    if (wide && 32 * Kp * 4 + 16 + SKG_WAVES * 2 * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(2);
-    else if (16 * Kp * 4 + 16 + SKG_WAVES * 64 * 4 * 4 <= SK_LDS_BUDGET) SKG_LAUNCH(1);
-    else return DSSVAE_ETOOBIG;
+    if (wide && 32 * Kp * 4 + 16 + SKG_WAVES * 2 * 64 * 4 * 4 + 256 <= SK_LDS_BUDGET) {
+        if (pick) SKG_LAUNCH(2, true); else SKG_LAUNCH(2, false);
+    } else if (16 * Kp * 4 + 16 + SKG_WAVES * 64 * 4 * 4 + 256 <= SK_LDS_BUDGET) {
+        if (pick) SKG_LAUNCH(1, true); else SKG_LAUNCH(1, false);
+    } else {
+        return DSSVAE_ETOOBIG;
+    }
 #undef SKG_LAUNCH
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
+}
+
+int skg_check(const float* Hprev, int64_t ldh, int H, const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
+              const float* bih, const float* bhh, int M, int In, float* Hnew, int64_t ldo) {
+    if (!Hprev || !Wih || !Whh || !bih || !bhh || !Hnew || M <= 0 || In <= 0 || H <= 0 || ldh < H || ldi < In ||
+        ldhh < H || ldo < H || Hnew == Hprev)
+        return DSSVAE_EINVAL;
+    if (M > DSSVAE_SKINNY_MAX_ROWS || (In % 4) || (H % 4) || (ldh % 4) || (ldi % 4) || (ldhh % 4) ||
+        !aligned16(Hprev) || !aligned16(Wih) || !aligned16(Whh))
+        return DSSVAE_ETOOBIG;
+    return DSSVAE_OK;
+}
+}  // namespace
+
+extern "C" int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H,
+                                      const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
+                                      const float* bih, const float* bhh, int M, float* Hnew, int64_t ldo,
+                                      void* stream) {
+    if (!X || ldx < In) return DSSVAE_EINVAL;
+    const int e = skg_check(Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, In, Hnew, ldo);
+    if (e != DSSVAE_OK) return e;
+    if ((ldx % 4) || !aligned16(X)) return DSSVAE_ETOOBIG;
+    return skg_launch(X, ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Hnew, ldo, nullptr,
+                      (hipStream_t)stream);
+}
+
+extern "C" int dssvae_skinny_gru_step_pick(const float* part_max, const int64_t* part_arg, int n_split,
+                                           int64_t* tokens_out, const float* table, int64_t ldt, int In,
+                                           float* x_out, int64_t ldxo, const float* Hprev, int64_t ldh, int H,
+                                           const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
+                                           const float* bih, const float* bhh, int M, float* Hnew, int64_t ldo,
+                                           void* stream) {
+    if (!part_max || !part_arg || n_split <= 0 || !tokens_out || !table || !x_out || ldt < In || ldxo < In)
+        return DSSVAE_EINVAL;
+    const int e = skg_check(Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, In, Hnew, ldo);
+    if (e != DSSVAE_OK) return e;
+    if ((ldt % 4) || (ldxo % 4) || !aligned16(table) || !aligned16(x_out)) return DSSVAE_ETOOBIG;
+    SkgPick pk;
+    pk.pm = part_max; pk.pa = part_arg; pk.S = n_split; pk.tok_out = tokens_out; pk.table = table; pk.ldt = ldt;
+    pk.xout = x_out; pk.ldxo = ldxo;
+    return skg_launch(nullptr, 0, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Hnew, ldo, &pk,
+                      (hipStream_t)stream);
 }

@@ -108,6 +108,8 @@ _SIGNATURES = {
     "dssvae_skinny_argmax_rows": ([_I, _I], _I),
     "dssvae_skinny_linear": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P], _I),
     "dssvae_skinny_gru_step": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P], _I),
+    "dssvae_skinny_gru_step_pick": ([_P, _P, _I, _P, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P, _L, _P, _P, _I, _P, _L,
+                                    _P], _I),
     "dssvae_skinny_argmax": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _P, _P, _P], _I),
     "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
     "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 6 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd */
+#define DSSVAE_ABI_VERSION 6 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -365,6 +365,18 @@ int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, 
 int dssvae_skinny_gru_step(const float* X, int64_t ldx, int In, const float* h_prev, int64_t ldh, int H,
                            const float* w_ih, int64_t ld_ih, const float* w_hh, int64_t ld_hh,
                            const float* b_ih, const float* b_hh, int M, float* h_new, int64_t ldo, void* stream);
+
+/* The same cell step for the greedy loop's first layer when the step's input tokens have not been picked yet:
+ * part_max / part_arg [M, n_split] are the previous step's arg-max partials (dssvae_skinny_argmax /
+ * dssvae_linear_lse_fwd with want_arg); the launch picks every sentence's token (best split, ties to the smaller
+ * split: decoder/rnn_decoder.py:73 `topk(1)` of :160-168), takes the token's row of `table` as the cell's input x
+ * (decoder/rnn_decoder.py:61 `self.embedding(input_var)`), and leaves tokens_out [M] and the rows x_out [M, In]
+ * behind for the projection that follows.  Same ranges and error codes as dssvae_skinny_gru_step. */
+int dssvae_skinny_gru_step_pick(const float* part_max, const int64_t* part_arg, int n_split, int64_t* tokens_out,
+                                const float* table, int64_t ldt, int In, float* x_out, int64_t ldxo,
+                                const float* Hprev, int64_t ldh, int H, const float* Wih, int64_t ldi,
+                                const float* Whh, int64_t ldhh, const float* bih, const float* bhh, int M,
+                                float* Hnew, int64_t ldo, void* stream);
 int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
                          float* part_sum, int64_t* part_arg, void* stream);

@@ -536,6 +536,43 @@ def test_skinny_gru_step(M, In, H):
                                       2048, L.ptr(d[4]), L.ptr(d[5]), M, L.ptr(out), 2048, L.stream()) == -2
 
 
+@pytest.mark.parametrize("M,In,H,S", [(1, 4, 4, 1), (50, 300, 600, 235), (33, 12, 20, 70), (128, 64, 1024, 300), (50, 300, 304, 64)])
+def test_skinny_gru_step_picks_its_tokens(M, In, H, S):
+    """the greedy loop's first cell launch of a step: tokens from the previous step's arg-max partials (best split, ties
+    to the smaller split), their embedding rows as x, tokens and rows left behind; vs torch + nn.GRUCell in fp64"""
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    V = 500
+    g = torch.Generator().manual_seed(M + S)
+    pm = torch.randn(M, S, generator=g)
+    if S > 3:
+        pm[:, S // 2] = pm.max(dim=1).values          # a tie per row: the smaller split must win
+        pm[0, :] = -3.2e38                            # nothing above the floor: the first split's column
+    pa = torch.randint(0, V, (M, S), generator=g)
+    table, h = rnd(V, In, seed=1), rnd(M, H, seed=2)
+    wih, whh = rnd(3 * H, In, seed=3, scale=0.3), rnd(3 * H, H, seed=4, scale=0.3)
+    bih, bhh = rnd(3 * H, seed=5), rnd(3 * H, seed=6)
+    best = torch.zeros(M, dtype=torch.long)
+    for m in range(M):
+        mx = pm[m].max()
+        best[m] = int((pm[m] == mx).nonzero()[0]) if mx > -3.0e38 else 0
+    tok = pa[torch.arange(M), best]
+    cell = torch.nn.GRUCell(In, H).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(wih), cell.weight_hh.copy_(whh), cell.bias_ih.copy_(bih), cell.bias_hh.copy_(bhh)
+        want = cell(table[tok].double(), h.double())
+    d = [t.to(DEV) for t in (pm, pa, table, h, wih, whh, bih, bhh)]
+    out = torch.full((M, H), float("nan"), device=DEV)
+    tok_out = torch.full((M,), -1, dtype=torch.long, device=DEV)
+    x_out = torch.full((M, In), float("nan"), device=DEV)
+    L.check(lib.dssvae_skinny_gru_step_pick(L.ptr(d[0]), L.ptr(d[1]), S, L.ptr(tok_out), L.ptr(d[2]), In, In, L.ptr(x_out),
+                                            In, L.ptr(d[3]), H, H, L.ptr(d[4]), In, L.ptr(d[5]), H, L.ptr(d[6]),
+                                            L.ptr(d[7]), M, L.ptr(out), H, L.stream()), "skinny_gru_step_pick")
+    assert torch.equal(tok_out.cpu(), tok)
+    assert torch.equal(x_out.cpu(), table[tok])
+    close(out, want, rtol=1e-4, atol=1e-5, what="picking cell step")
+
+
 def test_weighted_sums_loss_assembly():
     """out_j = sum_k coef[j][k] * sum(x_k) against fp64; gradients broadcast per input; an input whose live outputs
     all carry a zero coefficient gets None (not zeros); an output that received no gradient contributes nothing"""
