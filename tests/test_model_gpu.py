@@ -94,6 +94,11 @@ def test_reference_helper_surface_matches_loss_dict(case):
         adv_syn, adv_sem = pm.get_adv_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
         dis_syn, dis_sem = pm.get_dis_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
         d = pm._dis_loss(syn_h, sem_h, batch.syn_var, batch.tgt_var)
+        fwd = pm.forward(exs)   # the reference's forward() entries (syntax_vae.py:270-276, enhance_syntax_vae.py:276-288)
+    assert fwd["batch_size"] == B
+    assert rel_err(fwd["mul"] / B, want["MUL Loss"]) < 1e-4 and rel_err(fwd["adv"] / B, want["ADV Loss"]) < 1e-4
+    assert rel_err(fwd["nll_loss"] / B, want["NLL Loss"]) < 1e-4
+    assert rel_err(fwd["sem_loss"] + fwd["syn_loss"], fwd["mul"]) < 1e-5
     assert rel_err((mul_syn + mul_sem) / B, want["MUL Loss"]) < 1e-4
     assert rel_err((adv_syn + adv_sem) / B, want["ADV Loss"]) < 1e-4
     assert rel_err(dis_syn, dis["dis syn"]) < 1e-4 and rel_err(dis_sem, dis["dis sem"]) < 1e-4
