@@ -31,7 +31,9 @@ __global__ void embed_scatter_kernel(float* __restrict__ dtable, int64_t ldt, co
     for (int e = lane; e < E; e += 64) atomicAdd(dst + e, mk ? src[e] * mk[e] : src[e]);
 }
 
-__global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, float scale, uint64_t seed) {
+__global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p, float scale, uint64_t seed,
+                                    const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += seed_base[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         mask[i] = u01(seed, (uint64_t)i) < p ? 0.f : scale;
 }
@@ -39,16 +41,20 @@ __global__ void dropout_mask_kernel(float* __restrict__ mask, int64_t n, float p
 // y = x * keep-mask(seed) / (1 - p): the mask is a function of (seed, element index), so backward regenerates
 // it from the seed (dx = dy * mask) and no mask tensor ever exists
 __global__ void dropout_apply_kernel(const float* __restrict__ x, int64_t n, float p, float scale, uint64_t seed,
-                                     float* __restrict__ y) {
+                                     const uint64_t* __restrict__ seed_base, float* __restrict__ y) {
+    if (seed_base) seed += seed_base[0];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
         y[i] = u01(seed, (uint64_t)i) < p ? 0.f : x[i] * scale;
 }
 
 __global__ void unk_replace_kernel(const int64_t* __restrict__ ids, int64_t n, const float* __restrict__ rnd,
-                                   float rate, uint64_t seed, int64_t sos, int64_t pad, int64_t eos, int64_t unk,
-                                   int64_t* __restrict__ out) {
+                                   float rate, const float* __restrict__ rate_dev, uint64_t seed,
+                                   const uint64_t* __restrict__ seed_base, int64_t sos, int64_t pad, int64_t eos,
+                                   int64_t unk, int64_t* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (seed_base) seed += seed_base[0];
+    if (rate_dev) rate = rate_dev[0];
     const int64_t v = ids[i];
     const float r = rnd ? rnd[i] : u01(seed, (uint64_t)i);
     const bool special = v == sos || v == pad || v == eos;
@@ -251,7 +257,9 @@ __global__ __launch_bounds__(256) void sumsq_final_kernel(const float* __restric
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, int64_t n, float lr, float b1, float b2, float eps, float bc1,
                             float bc2_sqrt, const float* __restrict__ sumsq, float max_norm,
-                            const float* __restrict__ live, const int32_t* __restrict__ skip) {
+                            const float* __restrict__ live, const int32_t* __restrict__ skip,
+                            const float* __restrict__ hyper) {
+    if (hyper) { lr = hyper[0]; bc1 = hyper[1]; bc2_sqrt = hyper[2]; }  // per-step values of a replayed graph
     // a persistent launch of this step timed out waiting for a peer (its results are garbage): the whole
     // update is dropped on device, before the host gets to read the error word
     if (skip && skip[0] != 0) return;
@@ -285,6 +293,8 @@ struct WSums {
     const float* dout[DSSVAE_WSUMS_MAX];
     int len[DSSVAE_WSUMS_MAX];
     float coef[DSSVAE_WSUMS_MAX][DSSVAE_WSUMS_MAX];   // [out][in]
+    float coefd[DSSVAE_WSUMS_MAX][DSSVAE_WSUMS_MAX];  // [out][in]: the part multiplied by *dyn (the KL weight of the step)
+    const float* dyn;
     int n_in, n_out;
 };
 
@@ -301,7 +311,8 @@ __global__ __launch_bounds__(1024) void weighted_sums_fwd_kernel(WSums a, float*
     __syncthreads();
     if ((int)threadIdx.x < a.n_out) {
         float v = 0.f;
-        for (int k = 0; k < a.n_in; ++k) v += a.coef[threadIdx.x][k] * comp[k];
+        const float d = a.dyn ? a.dyn[0] : 0.f;
+        for (int k = 0; k < a.n_in; ++k) v += (a.coef[threadIdx.x][k] + a.coefd[threadIdx.x][k] * d) * comp[k];
         out[threadIdx.x] = v;
     }
 }
@@ -312,8 +323,9 @@ __global__ __launch_bounds__(256) void weighted_sums_bwd_kernel(WSums a) {
     const int k = blockIdx.y;
     if (!a.din[k]) return;
     float g = 0.f;
+    const float d = a.dyn ? a.dyn[0] : 0.f;
     for (int j = 0; j < a.n_out; ++j)
-        if (a.dout[j]) g += a.dout[j][0] * a.coef[j][k];
+        if (a.dout[j]) g += a.dout[j][0] * (a.coef[j][k] + a.coefd[j][k] * d);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < a.len[k]; i += gridDim.x * 256) a.din[k][i] = g;
 }
 
@@ -349,29 +361,45 @@ extern "C" int dssvae_embed_scatter_add(float* dtable, int64_t ldt, const int64_
     return DSSVAE_OK;
 }
 
-extern "C" int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
+extern "C" int dssvae_dropout_mask_dyn(float* mask, int64_t n, float p, uint64_t seed, const uint64_t* seed_base,
+                                       void* stream) {
     if (!mask || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, mask, n, p,
-                       1.f / (1.f - p), seed);
+                       1.f / (1.f - p), seed, seed_base);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    return dssvae_dropout_mask_dyn(mask, n, p, seed, nullptr, stream);
+}
+
+extern "C" int dssvae_dropout_apply_dyn(const float* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_base,
+                                        float* y, void* stream) {
+    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, n, p,
+                       1.f / (1.f - p), seed, seed_base, y);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
 
 extern "C" int dssvae_dropout_apply(const float* x, int64_t n, float p, uint64_t seed, float* y, void* stream) {
-    if (!x || !y || n <= 0 || p < 0.f || p >= 1.f) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(dropout_apply_kernel, dim3(grid_for(n, 256, 8192)), dim3(256), 0, (hipStream_t)stream, x, n, p,
-                       1.f / (1.f - p), seed, y);
+    return dssvae_dropout_apply_dyn(x, n, p, seed, nullptr, y, stream);
+}
+
+extern "C" int dssvae_unk_replace_dyn(const int64_t* ids, int64_t n, const float* rnd, float rate,
+                                      const float* rate_dev, uint64_t seed, const uint64_t* seed_base, int64_t sos,
+                                      int64_t pad, int64_t eos, int64_t unk, int64_t* out, void* stream) {
+    if (!ids || !out || n <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(unk_replace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids,
+                       n, rnd, rate, rate_dev, seed, seed_base, sos, pad, eos, unk, out);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
 
 extern "C" int dssvae_unk_replace(const int64_t* ids, int64_t n, const float* rnd, float rate, uint64_t seed,
                                   int64_t sos, int64_t pad, int64_t eos, int64_t unk, int64_t* out, void* stream) {
-    if (!ids || !out || n <= 0) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(unk_replace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ids,
-                       n, rnd, rate, seed, sos, pad, eos, unk, out);
-    DSSVAE_CHECK_LAUNCH();
-    return DSSVAE_OK;
+    return dssvae_unk_replace_dyn(ids, n, rnd, rate, nullptr, seed, nullptr, sos, pad, eos, unk, out, stream);
 }
 
 extern "C" int dssvae_reparam_kl_fwd(const float* mean, const float* logv, const float* eps, int64_t n, float* z,
@@ -476,13 +504,23 @@ extern "C" int dssvae_adam_step(float* p, const float* g, float* m, float* v, in
     const float bc1 = 1.f - powf(beta1, (float)step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, (float)step));
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
-                       beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask, skip_flag);
+                       beta2, eps, bc1, bc2_sqrt, sumsq, max_norm, grad_scale_mask, skip_flag, (const float*)nullptr);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper,
+                                    float beta1, float beta2, float eps, const float* sumsq, float max_norm,
+                                    const int32_t* skip_flag, void* stream) {
+    if (!p || !g || !m || !v || !hyper || n <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, 0.f, beta1,
+                       beta2, eps, 1.f, 1.f, sumsq, max_norm, (const float*)nullptr, skip_flag, hyper);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
 
 static int wsums_pack(WSums* a, const float* const* in, float* const* din, const int32_t* len, int n_in,
-                      const float* coef, int n_out) {
+                      const float* coef, int n_out, const float* coef_dyn = nullptr, const float* dyn = nullptr) {
     if (!len || !coef || n_in <= 0 || n_out <= 0) return DSSVAE_EINVAL;
     if (n_in > DSSVAE_WSUMS_MAX || n_out > DSSVAE_WSUMS_MAX) return DSSVAE_ETOOBIG;
     a->n_in = n_in;
@@ -494,15 +532,25 @@ static int wsums_pack(WSums* a, const float* const* in, float* const* din, const
         a->len[k] = len[k];
     }
     for (int j = 0; j < n_out; ++j)
-        for (int k = 0; k < n_in; ++k) a->coef[j][k] = coef[j * n_in + k];
+        for (int k = 0; k < n_in; ++k) {
+            a->coef[j][k] = coef[j * n_in + k];
+            a->coefd[j][k] = (coef_dyn && dyn) ? coef_dyn[j * n_in + k] : 0.f;
+        }
+    a->dyn = (coef_dyn && dyn) ? dyn : nullptr;
     return DSSVAE_OK;
 }
 
 extern "C" int dssvae_weighted_sums_fwd(const float* const* in, const int32_t* len, int n_in, const float* coef,
                                         int n_out, float* out, void* stream) {
+    return dssvae_weighted_sums_fwd_dyn(in, len, n_in, coef, nullptr, nullptr, n_out, out, stream);
+}
+
+extern "C" int dssvae_weighted_sums_fwd_dyn(const float* const* in, const int32_t* len, int n_in, const float* coef,
+                                            const float* coef_dyn, const float* dyn, int n_out, float* out,
+                                            void* stream) {
     if (!in || !out) return DSSVAE_EINVAL;
     WSums a = {};
-    const int e = wsums_pack(&a, in, nullptr, len, n_in, coef, n_out);
+    const int e = wsums_pack(&a, in, nullptr, len, n_in, coef, n_out, coef_dyn, dyn);
     if (e != DSSVAE_OK) return e;
     hipLaunchKernelGGL(weighted_sums_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, a, out);
     DSSVAE_CHECK_LAUNCH();
@@ -511,9 +559,15 @@ extern "C" int dssvae_weighted_sums_fwd(const float* const* in, const int32_t* l
 
 extern "C" int dssvae_weighted_sums_bwd(float* const* din, const int32_t* len, int n_in, const float* coef, int n_out,
                                         const float* const* dout, void* stream) {
+    return dssvae_weighted_sums_bwd_dyn(din, len, n_in, coef, nullptr, nullptr, n_out, dout, stream);
+}
+
+extern "C" int dssvae_weighted_sums_bwd_dyn(float* const* din, const int32_t* len, int n_in, const float* coef,
+                                            const float* coef_dyn, const float* dyn, int n_out,
+                                            const float* const* dout, void* stream) {
     if (!din || !dout) return DSSVAE_EINVAL;
     WSums a = {};
-    const int e = wsums_pack(&a, nullptr, din, len, n_in, coef, n_out);
+    const int e = wsums_pack(&a, nullptr, din, len, n_in, coef, n_out, coef_dyn, dyn);
     if (e != DSSVAE_OK) return e;
     for (int j = 0; j < n_out; ++j) a.dout[j] = dout[j];
     int longest = 0;
@@ -522,6 +576,116 @@ extern "C" int dssvae_weighted_sums_bwd(float* const* din, const int32_t* len, i
     if (longest == 0) return DSSVAE_OK;
     const int bx = (longest + 255) / 256;
     hipLaunchKernelGGL(weighted_sums_bwd_kernel, dim3(bx > 64 ? 64 : bx, n_in), dim3(256), 0, (hipStream_t)stream, a);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-step scalars of a replayed HIP graph, and minibatches cut from the device-resident id cache
+// ---------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct StepWords { uint32_t w[DSSVAE_STEP_WORDS]; };
+
+__global__ void set_words_kernel(uint32_t* __restrict__ dst, StepWords v, int n) {
+    if ((int)threadIdx.x < n) dst[threadIdx.x] = v.w[threadIdx.x];
+}
+
+// one wave per output row: row b = [sos] ids[off[e] .. off[e+1]) [eos] pad.., cut at W
+__global__ void batch_rows_kernel(const int64_t* __restrict__ flat, const int64_t* __restrict__ off,
+                                  const int64_t* __restrict__ idx, int B, int W, int boundary, int64_t sos,
+                                  int64_t eos, int64_t pad, int64_t* __restrict__ out, int32_t* __restrict__ lens) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t e = idx[b], lo = off[e];
+    const int64_t L = off[e + 1] - lo;
+    if (lane == 0 && lens) lens[b] = (int32_t)L;
+    int64_t* row = out + (int64_t)b * W;
+    for (int t = lane; t < W; t += 64) {
+        const int64_t k = boundary ? t - 1 : t;   // position within the example
+        int64_t v = pad;
+        if (boundary && t == 0) v = sos;
+        else if (k < L) v = flat[lo + k];
+        else if (boundary && k == L) v = eos;
+        row[t] = v;
+    }
+}
+
+// keep[] = the positions b*T + t, t < min(len[b] + 1, T), in order; one workgroup scans the B lengths in LDS
+__global__ __launch_bounds__(1024) void keep_rows_kernel(const int32_t* __restrict__ lens, int B, int T,
+                                                         int64_t* __restrict__ keep, int n_keep) {
+    __shared__ int start[8192 + 1];
+    __shared__ int wave_tot[16];
+    __shared__ int carry_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < B; base += 1024) {
+        const int b = base + threadIdx.x;
+        const int c = b < B ? min(lens[b] + 1, T) : 0;
+        int incl = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += t;
+        }
+        if (lane == 63) wave_tot[wave] = incl;
+        __syncthreads();
+        int before = carry_s;
+        for (int w = 0; w < wave; ++w) before += wave_tot[w];
+        if (b < B) start[b] = before + incl - c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = carry_s;
+            for (int w = 0; w < 16; ++w) tot += wave_tot[w];
+            carry_s = tot;
+        }
+        __syncthreads();
+    }
+    const int total = carry_s;
+    if (threadIdx.x == 0) start[B] = total;
+    __syncthreads();
+    // one wave per sentence writes its run of positions
+    for (int b = wave; b < B; b += 16) {
+        const int s0 = start[b], c = start[b + 1] - s0;
+        for (int t = lane; t < c; t += 64)
+            if (s0 + t < n_keep) keep[s0 + t] = (int64_t)b * T + t;
+    }
+    // the caller may have asked for more positions than there are (a padded list): repeat the last real one
+    if (total > 0) {
+        int lb = B - 1;
+        while (lb > 0 && start[lb + 1] - start[lb] == 0) --lb;
+        const int64_t last = (int64_t)lb * T + (start[lb + 1] - start[lb] - 1);
+        for (int i = total + threadIdx.x; i < n_keep; i += 1024) keep[i] = last;
+    }
+}
+
+}  // namespace
+
+extern "C" int dssvae_set_words(uint32_t* dst, const uint32_t* words_host, int n, void* stream) {
+    if (!dst || !words_host || n <= 0 || n > DSSVAE_STEP_WORDS) return DSSVAE_EINVAL;
+    StepWords v = {};
+    for (int i = 0; i < n; ++i) v.w[i] = words_host[i];
+    hipLaunchKernelGGL(set_words_kernel, dim3(1), dim3(DSSVAE_STEP_WORDS), 0, (hipStream_t)stream, dst, v, n);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_batch_rows(const int64_t* flat_ids, const int64_t* offsets, const int64_t* idx, int B, int W,
+                                 int boundary, int64_t sos, int64_t eos, int64_t pad, int64_t* out,
+                                 int32_t* lengths_out, void* stream) {
+    if (!flat_ids || !offsets || !idx || !out || B <= 0 || W <= 0) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(batch_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, (hipStream_t)stream, flat_ids, offsets, idx,
+                       B, W, boundary, sos, eos, pad, out, lengths_out);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_keep_rows(const int32_t* lengths, int B, int T, int64_t* keep, int n_keep, void* stream) {
+    if (!lengths || !keep || B <= 0 || T <= 0 || n_keep <= 0) return DSSVAE_EINVAL;
+    if (B > 8192) return DSSVAE_ETOOBIG;
+    hipLaunchKernelGGL(keep_rows_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, lengths, B, T, keep, n_keep);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

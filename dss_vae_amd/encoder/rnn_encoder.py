@@ -37,7 +37,9 @@ class RNNEncoder(RNNBase):
         dev = input_var.device
         lens = None
         if self.variable_lengths and input_lengths is not None:
-            lens = torch.as_tensor(list(input_lengths), dtype=torch.int32).to(dev, non_blocking=True)
+            lens = getattr(input_lengths, "dev", None)
+            if lens is None:
+                lens = torch.as_tensor(list(input_lengths), dtype=torch.int32).to(dev, non_blocking=True)
             input_var = input_var[:, :int(max(input_lengths))].contiguous()
         x = lookup(self.embedding, input_var, GLOBAL_SEEDS)
         hn, cn = [], []
@@ -65,7 +67,9 @@ def encode_many(encoders, input_var, input_lengths=None):
     B, Lmax = input_var.shape
     lens = None
     if input_lengths is not None and all(e.variable_lengths for e in encoders):
-        lens = torch.as_tensor(list(input_lengths), dtype=torch.int32).to(dev, non_blocking=True)
+        lens = getattr(input_lengths, "dev", None)  # vae/base_vae.py: Lengths (the batch's own device copy)
+        if lens is None:
+            lens = torch.as_tensor(list(input_lengths), dtype=torch.int32).to(dev, non_blocking=True)
         Lmax = int(max(input_lengths))
         input_var = input_var[:, :Lmax].contiguous()
     # one gather per distinct embedding table

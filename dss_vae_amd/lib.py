@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 6  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 7  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -42,6 +42,7 @@ CELL_GRU, CELL_LSTM = 0, 1
 
 GEMM_MAX_GROUP = 8
 SUMSQ_PARTIALS = 2048
+STEP_WORDS = 128  # DSSVAE_STEP_WORDS
 
 
 class GemmProblem(C.Structure):
@@ -118,6 +119,17 @@ _SIGNATURES = {
     "dssvae_decode_profile_read": ([C.POINTER(C.c_double), C.POINTER(C.c_int)], _I),
     "dssvae_sumsq": ([_P, _L, _P, _P, _P], _I),
     "dssvae_adam_step": ([_P, _P, _P, _P, _L, _F, _F, _F, _F, _I, _P, _F, _P, _P, _P], _I),
+    "dssvae_set_words": ([_P, C.POINTER(C.c_uint32), _I, _P], _I),
+    "dssvae_dropout_mask_dyn": ([_P, _L, _F, _U64, _P, _P], _I),
+    "dssvae_dropout_apply_dyn": ([_P, _L, _F, _U64, _P, _P, _P], _I),
+    "dssvae_unk_replace_dyn": ([_P, _L, _P, _F, _P, _U64, _P, _L, _L, _L, _L, _P, _P], _I),
+    "dssvae_weighted_sums_fwd_dyn": ([C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), _P, _I, _P, _P], _I),
+    "dssvae_weighted_sums_bwd_dyn": ([C.POINTER(C.c_void_p), C.POINTER(C.c_int32), _I, C.POINTER(C.c_float),
+                                      C.POINTER(C.c_float), _P, _I, C.POINTER(C.c_void_p), _P], _I),
+    "dssvae_adam_step_dyn": ([_P, _P, _P, _P, _L, _P, _F, _F, _F, _P, _F, _P, _P], _I),
+    "dssvae_batch_rows": ([_P, _P, _P, _I, _I, _I, _L, _L, _L, _P, _P, _P], _I),
+    "dssvae_keep_rows": ([_P, _I, _I, _P, _I, _P], _I),
 }
 EXPORTS = tuple(_SIGNATURES)
 

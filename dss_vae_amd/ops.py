@@ -69,6 +69,101 @@ class _Span(object):
         return False
 
 
+# ----------------------------------------------------------------------------------------------
+# Per-step scalars read on the device (include/dssvae_hip.h: dssvae_set_words and the *_dyn entry points).
+# While a training step is being CAPTURED into a HIP graph (train.GraphedTrainer) `DYN` is the graph's StepScalars:
+# every value that changes from step to step is then a slot of its device buffer instead of a host scalar baked into
+# a kernel argument, and one `upload()` launch in front of each replay rewrites the slots.  Outside a capture `DYN`
+# is None and every op passes its host values as before (bit-identical to the plain entry points).
+# ----------------------------------------------------------------------------------------------
+class Dyn(float):
+    """a python float that also names a slot of the capturing graph's StepScalars: ops that can read the value on the
+    device take the slot's address, everything else sees the number"""
+
+    def __new__(cls, value, slot):
+        obj = float.__new__(cls, value)
+        obj.slot = slot
+        return obj
+
+
+class StepScalars(object):
+    SEED_WORDS = 2                       # words 0-1: the 64-bit base of the step's dropout / word-dropout seeds
+    SEED_STRIDE = 0xD1B54A32D192ED03     # k-th seed of a captured step = base + k * SEED_STRIDE (mod 2^64)
+
+    def __init__(self, device):
+        self.buf = torch.zeros(L.STEP_WORDS, device=device, dtype=torch.int32)
+        self.f32 = self.buf.view(torch.float32)
+        self.host = (C.c_uint32 * L.STEP_WORDS)()
+        self.slots = {}
+        self.n = self.SEED_WORDS
+        self.seed_k = 0
+        self.adam = []       # train.FlatAdam.step: (slot, parameter indices) per Adam range of the captured step
+        self.keepalive = []  # events recorded under capture: destroying one before the capture ends leaves the
+        #                      runtime's capture bookkeeping with a dangling pointer (a crash in hipStreamEndCapture)
+
+    def slot(self, name, words=1):
+        if name not in self.slots:
+            if self.n + words > L.STEP_WORDS:
+                raise RuntimeError("StepScalars: more than %d per-step words" % L.STEP_WORDS)
+            self.slots[name] = self.n
+            self.n += words
+        return self.slots[name]
+
+    def ptr(self, slot):
+        return C.c_void_p(self.buf.data_ptr() + 4 * slot)
+
+    def set_float(self, slot, value):
+        self.host[slot] = C.c_uint32.from_buffer_copy(C.c_float(value)).value
+
+    def set_seed_base(self, base):
+        base &= 2 ** 64 - 1
+        self.host[0], self.host[1] = base & 0xFFFFFFFF, base >> 32
+
+    def next_seed(self):
+        """-> (seed offset of the next RNG use of the captured step, device pointer to the base)"""
+        self.seed_k += 1
+        return (self.seed_k * self.SEED_STRIDE) & (2 ** 64 - 1), self.ptr(0)
+
+    def value(self, name, value):
+        slot = self.slot(name)
+        self.set_float(slot, value)
+        return Dyn(value, slot)
+
+    def tensor(self, d):
+        """0-d float32 view of a Dyn's slot, for torch ops that take the value as a tensor"""
+        return self.f32[d.slot]
+
+    def upload(self):
+        L.check(L.load().dssvae_set_words(L.ptr(self.buf), self.host, self.n, L.stream()), "dssvae_set_words")
+
+
+DYN = None
+
+
+def _event():
+    """an event for cross-stream ordering; under capture it lives as long as the graph's record"""
+    ev = torch.cuda.Event()
+    if DYN is not None:
+        DYN.keepalive.append(ev)
+    return ev
+
+
+def dyn_value(name, value):
+    """`value` as is, or -- while a step is being captured -- tagged with its per-step slot"""
+    return value if DYN is None else DYN.value(name, float(value))
+
+
+def dyn_tensor(v):
+    """a scalar for torch arithmetic: the number itself, or the device view of its per-step slot"""
+    return DYN.tensor(v) if (DYN is not None and isinstance(v, Dyn)) else v
+
+
+def _seed_args(seed):
+    if DYN is None:
+        return int(seed) & (2 ** 64 - 1), None
+    return DYN.next_seed()
+
+
 def n_cus():
     global _CUS
     if _CUS is None:
@@ -235,11 +330,12 @@ def _ones_col(M, dev):
     GEMM as one more output column"""
     # one per stream: the fill is stream-ordered, another stream would read the column before it is written
     key = (dev, torch.cuda.current_stream().cuda_stream)
-    t = _ONES_COL.get(key)
+    t = None if DYN is not None else _ONES_COL.get(key)
     if t is None or t.size(0) < M:
         t = torch.zeros(max(M, 8192), 4, device=dev, dtype=torch.float32)
         t[:, 0] = 1.0
-        _ONES_COL[key] = t
+        if DYN is None:  # (under capture the fill is a node of the graph and the memory the graph's own)
+            _ONES_COL[key] = t
     return t[:M]
 
 
@@ -374,7 +470,8 @@ def embed(table, ids, mask=None):
 
 def dropout_mask(shape, p, seed, device):
     m = torch.empty(shape, device=device, dtype=torch.float32)
-    L.check(L.load().dssvae_dropout_mask(L.ptr(m), m.numel(), float(p), int(seed) & (2 ** 64 - 1), L.stream()),
+    seed, base = _seed_args(seed)
+    L.check(L.load().dssvae_dropout_mask_dyn(L.ptr(m), m.numel(), float(p), seed, base, L.stream()),
             "dssvae_dropout_mask")
     return m
 
@@ -388,9 +485,10 @@ class _DropoutFn(Function):
         ctx.set_materialize_grads(False)
         x = _f32(x).contiguous()
         y = torch.empty_like(x)
-        ctx.p, ctx.seed = float(p), int(seed) & (2 ** 64 - 1)
-        L.check(L.load().dssvae_dropout_apply(L.ptr(x), x.numel(), ctx.p, ctx.seed, L.ptr(y), L.stream()),
-                "dssvae_dropout_apply")
+        ctx.p = float(p)
+        ctx.seed, ctx.seed_base = _seed_args(seed)
+        L.check(L.load().dssvae_dropout_apply_dyn(L.ptr(x), x.numel(), ctx.p, ctx.seed, ctx.seed_base, L.ptr(y),
+                                                  L.stream()), "dssvae_dropout_apply")
         return y
 
     @staticmethod
@@ -399,8 +497,8 @@ class _DropoutFn(Function):
             return None, None, None
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        L.check(L.load().dssvae_dropout_apply(L.ptr(dy), dy.numel(), ctx.p, ctx.seed, L.ptr(dx), L.stream()),
-                "dssvae_dropout_apply")
+        L.check(L.load().dssvae_dropout_apply_dyn(L.ptr(dy), dy.numel(), ctx.p, ctx.seed, ctx.seed_base, L.ptr(dx),
+                                                  L.stream()), "dssvae_dropout_apply")
         return dx, None, None
 
 
@@ -413,16 +511,18 @@ def dropout(x, p, seed):
 
 def unk_replace(ids, rate, entry, rand=None, seed=0):
     """word dropout on device (utils/nn_funcs.py:13-23)."""
-    if not rate > 0.0:
+    rate_dev = DYN.ptr(rate.slot) if (DYN is not None and isinstance(rate, Dyn)) else None
+    if rate_dev is None and not rate > 0.0:
         return ids
     L.require_cuda(ids)
     ids = ids.contiguous()
     out = torch.empty_like(ids)
     if rand is not None:
         rand = rand.to(device=ids.device, dtype=torch.float32).contiguous()
-    L.check(L.load().dssvae_unk_replace(L.ptr(ids), ids.numel(), L.ptr(rand), float(rate), int(seed) & (2 ** 64 - 1),
-                                        entry.sos_id, entry.pad_id, entry.eos_id, entry.unk_id, L.ptr(out),
-                                        L.stream()), "dssvae_unk_replace")
+    seed, base = _seed_args(seed)
+    L.check(L.load().dssvae_unk_replace_dyn(L.ptr(ids), ids.numel(), L.ptr(rand), float(rate), rate_dev, seed, base,
+                                            entry.sos_id, entry.pad_id, entry.eos_id, entry.unk_id, L.ptr(out),
+                                            L.stream()), "dssvae_unk_replace")
     return out
 
 
@@ -463,7 +563,7 @@ class _WeightedSumsFn(Function):
     ones) and hands their addresses to the kernel: no stacking, no select-backward zero fills."""
 
     @staticmethod
-    def forward(ctx, coef, *xs):
+    def forward(ctx, coef, coef_dyn, dyn_ptr, *xs):
         ctx.set_materialize_grads(False)
         L.require_cuda(*xs)
         flat = [_f32(x).reshape(-1).contiguous() for x in xs]
@@ -472,9 +572,13 @@ class _WeightedSumsFn(Function):
         ptrs = (C.c_void_p * n_in)(*[x.data_ptr() for x in flat])
         lens = (C.c_int32 * n_in)(*[x.numel() for x in flat])
         cf = (C.c_float * (n_in * n_out))(*[float(c) for row in coef for c in row])
-        L.check(L.load().dssvae_weighted_sums_fwd(ptrs, lens, n_in, cf, n_out, L.ptr(out), L.stream()),
-                "dssvae_weighted_sums_fwd")
-        ctx.coef, ctx.cf, ctx.lens = coef, cf, lens
+        cfd = None if coef_dyn is None else (C.c_float * (n_in * n_out))(*[float(c) for row in coef_dyn for c in row])
+        L.check(L.load().dssvae_weighted_sums_fwd_dyn(ptrs, lens, n_in, cf, cfd, dyn_ptr, n_out, L.ptr(out),
+                                                      L.stream()), "dssvae_weighted_sums_fwd")
+        if coef_dyn is not None:  # which inputs a live output reads: either part of the coefficient counts
+            coef = tuple(tuple(1.0 if (a != 0.0 or b != 0.0) else 0.0 for a, b in zip(ra, rb))
+                         for ra, rb in zip(coef, coef_dyn))
+        ctx.coef, ctx.cf, ctx.lens, ctx.cfd, ctx.dyn_ptr = coef, cf, lens, cfd, dyn_ptr
         ctx.shapes = [x.shape for x in xs]
         ctx.dev = out.device
         return tuple(out[j] for j in range(n_out))
@@ -485,9 +589,9 @@ class _WeightedSumsFn(Function):
         live_out = [j for j in range(n_out) if douts[j] is not None]
         # an input none of whose live outputs carries a non-zero coefficient gets NO gradient (None, not zeros):
         # the optimiser's "no gradient = parameter skipped" semantics depend on it (adversary terms before warm_up)
-        want = [ctx.needs_input_grad[1 + k] and any(ctx.coef[j][k] != 0.0 for j in live_out) for k in range(n_in)]
+        want = [ctx.needs_input_grad[3 + k] and any(ctx.coef[j][k] != 0.0 for j in live_out) for k in range(n_in)]
         if not any(want):
-            return (None,) * (1 + n_in)
+            return (None,) * (3 + n_in)
         sizes = [ctx.lens[k] if want[k] else 0 for k in range(n_in)]
         buf = torch.empty(sum(sizes), device=ctx.dev, dtype=torch.float32)
         grads, off = [], 0
@@ -497,14 +601,23 @@ class _WeightedSumsFn(Function):
         g = [None if d is None else _f32(d).contiguous() for d in douts]
         dptr = (C.c_void_p * n_out)(*[None if d is None else d.data_ptr() for d in g])
         iptr = (C.c_void_p * n_in)(*[None if x is None else x.data_ptr() for x in grads])
-        L.check(L.load().dssvae_weighted_sums_bwd(iptr, ctx.lens, n_in, ctx.cf, n_out, dptr, L.stream()),
-                "dssvae_weighted_sums_bwd")
-        return (None, *grads)
+        L.check(L.load().dssvae_weighted_sums_bwd_dyn(iptr, ctx.lens, n_in, ctx.cf, ctx.cfd, ctx.dyn_ptr, n_out, dptr,
+                                                      L.stream()), "dssvae_weighted_sums_bwd")
+        return (None, None, None, *grads)
 
 
-def weighted_sums(coef, xs):
-    """coef[j][k] (python floats), xs[k] (tensors of any shape) -> tuple of 0-d tensors out_j = sum_k coef[j][k] * xs[k].sum()"""
-    return _WeightedSumsFn.apply(tuple(tuple(float(c) for c in row) for row in coef), *xs)
+def weighted_sums(coef, xs, coef_dyn=None, dyn=None):
+    """coef[j][k] (python floats), xs[k] (tensors of any shape) -> tuple of 0-d tensors out_j = sum_k coef[j][k] * xs[k].sum().
+    coef_dyn / dyn (a Dyn): the coefficient is coef + coef_dyn * dyn, with dyn read on the device when a step is being
+    captured (its value folded into coef on the host otherwise)."""
+    coef = tuple(tuple(float(c) for c in row) for row in coef)
+    if coef_dyn is None or dyn is None:
+        return _WeightedSumsFn.apply(coef, None, None, *xs)
+    if DYN is None or not isinstance(dyn, Dyn):
+        d = float(dyn)
+        return _WeightedSumsFn.apply(tuple(tuple(a + b * d for a, b in zip(ra, rb)) for ra, rb in zip(coef, coef_dyn)),
+                                     None, None, *xs)
+    return _WeightedSumsFn.apply(coef, tuple(tuple(float(c) for c in row) for row in coef_dyn), DYN.ptr(dyn.slot), *xs)
 
 
 def reparam_kl(mean, logv, eps):
@@ -706,7 +819,7 @@ class _LinearCEFn(Function):
                             L.ptr(xcat[m0:]) if need_w else None, xcat.stride(0) if need_w else 0, Kw,
                             L.ptr(dWp) if need_w else None, Kw, L.stream()), "dssvae_ce_onehot_fixup")
                     if need_w and n_str > 1:
-                        wg_done = torch.cuda.Event()
+                        wg_done = _event()
                         wg_done.record(st)
             for st in streams[1:]:
                 main.wait_stream(st)
@@ -1128,7 +1241,7 @@ class _PersistentTurn(object):
         return self
 
     def __exit__(self, *exc):
-        ev = torch.cuda.Event()
+        ev = _event()
         ev.record()
         _PERSISTENT_DONE[self.key] = ev
         return False
@@ -1542,6 +1655,36 @@ def sumsq(flat, out):
     if ws is None:
         ws = _SUMSQ_WS[flat.device] = torch.empty(L.SUMSQ_PARTIALS, device=flat.device)
     L.check(L.load().dssvae_sumsq(L.ptr(flat), flat.numel(), L.ptr(ws), L.ptr(out), L.stream()), "dssvae_sumsq")
+
+
+def adam_step_dyn(p, g, m, v, hyper_ptr, beta1, beta2, eps, sumsq_t, max_norm, skip_flag=None):
+    """Adam over one range with (lr, 1 - beta1^t, sqrt(1 - beta2^t)) read from three per-step device floats"""
+    L.check(L.load().dssvae_adam_step_dyn(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), hyper_ptr, beta1, beta2,
+                                          eps, L.ptr(sumsq_t), max_norm, L.ptr(skip_flag), L.stream()),
+            "dssvae_adam_step_dyn")
+
+
+def batch_rows(flat_ids, offsets, idx, width, boundary, entry, out=None, lengths_out=None):
+    """rows of a minibatch cut from the device-resident id cache (dssvae_batch_rows) -> int64 [B, width]"""
+    L.require_cuda(flat_ids, offsets, idx)
+    B = idx.numel()
+    if out is None:
+        out = torch.empty(B, width, device=idx.device, dtype=torch.int64)
+    assert out.shape == (B, width) and out.is_contiguous() and out.dtype == torch.int64
+    L.check(L.load().dssvae_batch_rows(L.ptr(flat_ids), L.ptr(offsets), L.ptr(idx), B, width, int(boundary),
+                                       entry.sos_id, entry.eos_id, entry.pad_id, L.ptr(out), L.ptr(lengths_out),
+                                       L.stream()), "dssvae_batch_rows")
+    return out
+
+
+def keep_rows(lengths_dev, T, n_keep, out=None):
+    """positions of the non-<pad> targets in the flattened [B, T] layout (dssvae_keep_rows) -> int64 [n_keep]"""
+    L.require_cuda(lengths_dev)
+    if out is None:
+        out = torch.empty(n_keep, device=lengths_dev.device, dtype=torch.int64)
+    L.check(L.load().dssvae_keep_rows(L.ptr(lengths_dev), lengths_dev.numel(), int(T), L.ptr(out), int(n_keep),
+                                      L.stream()), "dssvae_keep_rows")
+    return out
 
 
 def adam_step(p, g, m, v, lr, beta1, beta2, eps, step, sumsq_t, max_norm, skip_flag=None):

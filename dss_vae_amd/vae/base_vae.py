@@ -3,44 +3,125 @@
 eps / eps_syn / eps_sem / eps_syn_prior / rand_src / rand_tgt), absent keys are drawn on device."""
 import os
 
+import numpy as np
 import torch
 import torch.nn as nn
 
 from .. import ops
 from ..networks.rnn_base import GLOBAL_SEEDS
-from ..utils.nn_funcs import device, id2word, kl_anneal_function, to_input_variable, unk_replace
+from ..utils.nn_funcs import device, id2word, kl_anneal_function, to_input_variable, unk_replace, wd_anneal_function
+
+
+class Lengths(list):
+    """the sentence lengths of a minibatch as the host list the reference's interfaces pass around
+    (RNNEncoder.forward(input_var, input_lengths)), carrying the same numbers as a device int32 tensor (`dev`), so that
+    the packed recurrences never build one from the list (a host-to-device copy per step, and not capturable)"""
+    dev = None
+
+
+def _lengths(values, dev):
+    out = Lengths(int(v) for v in values)
+    out.dev = torch.from_numpy(np.asarray(out, dtype=np.int32)).pin_memory().to(dev, non_blocking=True)
+    return out
+
+
+def _n_keep(lengths, T):
+    """number of (sentence, step) rows of a [B, T] teacher-forced layout whose target is not <pad> (targets are
+    ids[:, 1:] of <s> w_1 .. w_L </s> <pad>..: L + 1 real targets per sentence), or None when no row is padding"""
+    n = int(np.minimum(np.asarray(lengths, dtype=np.int64) + 1, T).sum())
+    return None if n == len(lengths) * T else n
 
 
 def _keep_rows(lengths, T, dev):
-    """Row indices, in the flattened [B, T] layout of a teacher-forced decoder, whose target is not <pad>
-    (targets are ids[:, 1:] of <s> w_1 .. w_L </s> <pad>..: L + 1 real targets per sentence).  None when
-    no row is padding.  Known on the host from the lengths, so a ragged batch costs no device sync; the
-    scoring path projects only these rows onto the vocabulary (decoder/rnn_decoder.py: score_many)."""
-    if all(L + 1 >= T for L in lengths):
+    """Row indices, in the flattened [B, T] layout of a teacher-forced decoder, whose target is not <pad>.  None when
+    no row is padding.  Their NUMBER is known on the host from the lengths, so a ragged batch costs no device sync;
+    the list itself is written on the device (ops.keep_rows); the scoring path projects only these rows onto the
+    vocabulary (decoder/rnn_decoder.py: score_many)."""
+    n = _n_keep(lengths, T)
+    if n is None:
         return None
-    idx = [b * T + t for b, L in enumerate(lengths) for t in range(min(L + 1, T))]
-    return torch.as_tensor(idx, dtype=torch.int64).to(dev, non_blocking=True)
+    lens = lengths if isinstance(lengths, Lengths) else _lengths(lengths, dev)
+    return ops.keep_rows(lens.dev, T, n)
 
 
 class DeviceBatch(object):
     """Pre-tensorised minibatch resident in HBM (kills the per-step Python tensorisation of
-    utils/nn_funcs.py:143-174).  Accepted wherever a list of examples is."""
+    utils/nn_funcs.py:143-174).  Accepted wherever a list of examples is.  Built from token lists (this
+    constructor: evaluation, tests) or cut on the device from the dataset's id cache (structs/id_cache.py: training)."""
 
     def __init__(self, examples, vocab, with_tgt=True):
         self.examples = examples
+        self.n = len(examples)
         words = [e.src for e in examples]
-        self.length = [len(w) for w in words]
         self.src = to_input_variable(words, vocab.src, batch_first=True)
+        self.length = _lengths([len(w) for w in words], self.src.device)
         self.tgt_var = to_input_variable(words, vocab.src, append_boundary_sym=True, batch_first=True)
         self.tgt_var._keep_rows = _keep_rows(self.length, self.tgt_var.size(1) - 1, self.tgt_var.device)
-        self.syn_var = None
+        self.syn_var, self.tree_length = None, None
         if with_tgt and examples[0].tgt is not None:
             trees = [e.tgt for e in examples]
             self.syn_var = to_input_variable(trees, vocab.tgt, append_boundary_sym=True, batch_first=True)
-            self.syn_var._keep_rows = _keep_rows([len(t) for t in trees], self.syn_var.size(1) - 1, self.syn_var.device)
+            self.tree_length = _lengths([len(t) for t in trees], self.src.device)
+            self.syn_var._keep_rows = _keep_rows(self.tree_length, self.syn_var.size(1) - 1, self.syn_var.device)
+
+    @classmethod
+    def from_ids(cls, src, length, tgt_var, syn_var=None, tree_length=None):
+        """from tensors already on the device (structs/id_cache.py); length / tree_length: Lengths"""
+        self = cls.__new__(cls)
+        self.examples, self.n = None, src.size(0)
+        self.src, self.length, self.tgt_var, self.syn_var, self.tree_length = src, length, tgt_var, syn_var, tree_length
+        tgt_var._keep_rows = _keep_rows(length, tgt_var.size(1) - 1, src.device)
+        if syn_var is not None:
+            syn_var._keep_rows = _keep_rows(tree_length, syn_var.size(1) - 1, src.device)
+        return self
+
+    def signature(self):
+        """what a captured training step's launches depend on besides the values: the shapes"""
+        def keep(t):
+            k = None if t is None else getattr(t, "_keep_rows", None)
+            return None if k is None else k.numel()
+        return (self.n, tuple(self.src.shape), tuple(self.tgt_var.shape),
+                None if self.syn_var is None else tuple(self.syn_var.shape), keep(self.tgt_var), keep(self.syn_var))
+
+    def clone(self):
+        """a copy with storage of its own (the static inputs of a captured step)"""
+        def cp(t):
+            if t is None:
+                return None
+            out = t.clone()
+            k = getattr(t, "_keep_rows", None)
+            out._keep_rows = None if k is None else k.clone()
+            return out
+
+        def cl(l):
+            if l is None:
+                return None
+            out = Lengths(l)
+            out.dev = l.dev.clone()
+            return out
+        other = DeviceBatch.__new__(DeviceBatch)
+        other.examples, other.n = self.examples, self.n
+        other.src, other.tgt_var, other.syn_var = cp(self.src), cp(self.tgt_var), cp(self.syn_var)
+        other.length, other.tree_length = cl(self.length), cl(self.tree_length)
+        return other
+
+    def copy_from(self, other):
+        """overwrite this batch's device tensors with another batch's of the same signature (stream-ordered)"""
+        for a, b in ((self.src, other.src), (self.tgt_var, other.tgt_var), (self.syn_var, other.syn_var)):
+            if a is None:
+                continue
+            a.copy_(b, non_blocking=True)
+            ka = getattr(a, "_keep_rows", None)
+            if ka is not None:
+                ka.copy_(b._keep_rows, non_blocking=True)
+        for a, b in ((self.length, other.length), (self.tree_length, other.tree_length)):
+            if a is not None:
+                a[:] = list(b)
+                a.dev.copy_(b.dev, non_blocking=True)
+        self.examples = other.examples
 
     def __len__(self):
-        return len(self.examples)
+        return self.n
 
 
 class Linear(nn.Linear):
@@ -170,6 +251,16 @@ class BaseVAE(nn.Module):
             res = id2word(hyp, self.vocab.src)
             out.append([[res], [len(res)]])
         return out
+
+    GRAPH_SAFE = False  # True: one training step of the class can be captured into a HIP graph (train.GraphedTrainer)
+
+    def step_scalars(self, train_iter):
+        """the host scalars of a training step that change with train_iter: annealed word-dropout rate
+        (syntax_vae.py:278) and KL weight x kl_factor (:286).  get_loss reads them from here, and so does the replay of
+        a captured step, which writes them to the graph's per-step device slots (ops.StepScalars)."""
+        a = self.args
+        return {"unk_rate": wd_anneal_function(getattr(self, "unk_rate", 0.0), a.unk_schedule, train_iter, a.k, a.x0),
+                "kl_weight": self.get_kl_weight(train_iter) * a.kl_factor}
 
     def get_kl_weight(self, step):
         if self.step_kl_weight is None:

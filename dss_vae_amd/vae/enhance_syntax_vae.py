@@ -6,7 +6,6 @@ import torch
 
 from .. import ops
 from ..decoder.rnn_decoder import prepare_job, score_many
-from ..utils.nn_funcs import wd_anneal_function
 from .syntax_vae import BridgeMLP, BridgeRNN, TwoEncoderVAE
 
 
@@ -33,16 +32,27 @@ def _finish(job, logp):
 
 
 class _Row(dict):
-    """a linear combination {component index: coefficient} of the assembly's component sums"""
+    """a linear combination {component index: coefficient} of the assembly's component sums.  A key ("d", k) is the
+    part of component k's coefficient that is multiplied by the step's KL weight ON THE DEVICE (`dyn`, an ops.Dyn:
+    only while a step is being captured into a HIP graph; otherwise the weight is an ordinary factor)."""
+    dyn = None
 
     def __add__(self, other):
         out = _Row(self)
+        out.dyn = self.dyn if self.dyn is not None else other.dyn
         for k, c in other.items():
             out[k] = out.get(k, 0.0) + c
         return out
 
     def __mul__(self, c):
-        return _Row({k: v * c for k, v in self.items()})
+        if isinstance(c, ops.Dyn) and ops.DYN is not None:
+            assert not any(isinstance(k, tuple) for k in self), "one per-step factor per term"
+            out = _Row({("d", k): v for k, v in self.items()})
+            out.dyn = c
+            return out
+        out = _Row({k: v * c for k, v in self.items()})
+        out.dyn = self.dyn
+        return out
 
 
 class _Assembly:
@@ -62,7 +72,10 @@ class _Assembly:
     def run(self, rows=None):
         rows = self.rows if rows is None else rows
         names = list(rows)
-        vals = ops.weighted_sums([[rows[n].get(k, 0.0) for k in range(len(self.parts))] for n in names], self.parts)
+        ks = range(len(self.parts))
+        dyn = next((rows[n].dyn for n in names if rows[n].dyn is not None), None)
+        coef_dyn = None if dyn is None else [[rows[n].get(("d", k), 0.0) for k in ks] for n in names]
+        vals = ops.weighted_sums([[rows[n].get(k, 0.0) for k in ks] for n in names], self.parts, coef_dyn, dyn)
         return dict(zip(names, vals))
 
 
@@ -83,6 +96,7 @@ class MLPPredictor(BridgeMLP):
 
 
 class EnhanceSyntaxVAE(TwoEncoderVAE):
+    GRAPH_SAFE = True
     ENC_NAMES = ("sem_encoder", "syn_encoder")
     ADVERSARIES = ("sem_to_sent", "syn_to_sent", "syn_to_sem", "sem_to_syn")
 
@@ -211,12 +225,13 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
 
     def get_loss(self, examples, train_iter, is_dis=False, **kwargs):
         a = self.args
-        self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, train_iter, a.k, a.x0)
+        sc = self.step_scalars(train_iter)
+        self.step_unk_rate = ops.dyn_value("unk_rate", sc["unk_rate"])
         explore = self.forward(examples, is_dis, norm_by_word=False, defer_assembly=True)
         if is_dis:
             return explore
         asm, B = explore["assembly"], float(explore["batch_size"])
-        kl_weight = self.get_kl_weight(train_iter) * a.kl_factor
+        kl_weight = ops.dyn_value("kl_weight", sc["kl_weight"])
         sem_kl, syn_kl = asm.term((1.0, explore["sem_kl"]), 1.0), asm.term((1.0, explore["syn_kl"]), 1.0)
         r = asm.rows
         kl_loss = (sem_kl * a.sem_weight + syn_kl * a.syn_weight) * (1.0 / (a.sem_weight + a.syn_weight)) * (1.0 / B)
@@ -228,7 +243,7 @@ class EnhanceSyntaxVAE(TwoEncoderVAE):
         out = asm.run({"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
                        "KL Item": kl_item, "Model Score": kl_loss + nll_loss, "ELBO": kl_item + nll_loss, "Loss": loss,
                        "SYN KL Loss": syn_kl * (1.0 / B), "SEM KL Loss": sem_kl * (1.0 / B)})
-        out["KL Weight"] = kl_weight
+        out["KL Weight"] = float(kl_weight)
         return out
 
     def eval_syntax(self, examples):

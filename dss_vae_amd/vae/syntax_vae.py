@@ -228,6 +228,7 @@ class TwoEncoderVAE(BaseVAE):
 
 
 class SyntaxVAE(TwoEncoderVAE):
+    GRAPH_SAFE = True
     ENC_NAMES = ("word_encoder", "syntax_encoder")
 
     def __init__(self, args, vocab, src_embed=None, tgt_embed=None):
@@ -331,17 +332,19 @@ class SyntaxVAE(TwoEncoderVAE):
 
     def get_loss(self, examples, train_iter, is_dis=False, **kwargs):
         a = self.args
-        self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, train_iter, a.k, a.x0)
+        sc = self.step_scalars(train_iter)
+        self.step_unk_rate = ops.dyn_value("unk_rate", sc["unk_rate"])
         explore = self.forward(examples, is_dis)
         if is_dis:
             return explore
-        sem_kl, syn_kl, kl_loss, kl_weight = self._kl_terms(explore, train_iter)
+        sem_kl, syn_kl, kl_loss, _ = self._kl_terms(explore, train_iter)
+        kl_weight = ops.dyn_value("kl_weight", sc["kl_weight"])
         B = explore["batch_size"]
         kl_loss = kl_loss / B
         mul_loss, adv_loss, nll_loss = explore["mul"] / B, explore["adv"] / B, explore["nll_loss"] / B
-        kl_item = kl_loss * kl_weight
+        kl_item = kl_loss * ops.dyn_tensor(kl_weight)
         return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "MUL Loss": mul_loss, "ADV Loss": adv_loss,
-                "KL Weight": kl_weight, "KL Item": kl_item, "Model Score": kl_loss + nll_loss,
+                "KL Weight": float(kl_weight), "KL Item": kl_item, "Model Score": kl_loss + nll_loss,
                 "ELBO": kl_item + nll_loss, "Loss": kl_item + nll_loss + mul_loss - adv_loss,
                 "SYN KL Loss": syn_kl / B, "SEM KL Loss": sem_kl / B}
 

@@ -14,6 +14,7 @@ from .base_vae import BaseVAE, Linear
 
 
 class VanillaVAE(BaseVAE):
+    GRAPH_SAFE = True
     def __init__(self, args, vocab, word_embed=None):
         super().__init__(args, vocab, name="MySentVAE")
         src_embed = nn.Embedding(len(vocab.src), args.embed_size) if word_embed is None else word_embed
@@ -68,13 +69,14 @@ class VanillaVAE(BaseVAE):
 
     def get_loss(self, examples, step, **kwargs):
         a = self.args
-        self.step_unk_rate = wd_anneal_function(self.unk_rate, a.unk_schedule, step, a.k, a.x0)
+        sc = self.step_scalars(step)
+        self.step_unk_rate = ops.dyn_value("unk_rate", sc["unk_rate"])
         explore = self.forward(examples)
         B = explore["batch_size"]
-        kl_weight = self.get_kl_weight(step) * a.kl_factor
+        kl_weight = ops.dyn_value("kl_weight", sc["kl_weight"])
         nll_loss, kl_loss = explore["nll_loss"] / B, explore["kl"] / B
-        kl_item = kl_loss * kl_weight
-        return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "KL Weight": kl_weight, "Model Score": kl_loss + nll_loss,
+        kl_item = kl_loss * ops.dyn_tensor(kl_weight)
+        return {"KL Loss": kl_loss, "NLL Loss": nll_loss, "KL Weight": float(kl_weight), "Model Score": kl_loss + nll_loss,
                 "ELBO": kl_item + nll_loss, "Loss": kl_item + nll_loss, "KL Item": kl_item}
 
     def sample_latent(self, batch_size):

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 6 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick */
+#define DSSVAE_ABI_VERSION 7 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache) */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -435,6 +435,55 @@ int dssvae_sumsq(const float* g, int64_t n, float* partials, float* sumsq_out, v
 int dssvae_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                      float beta2, float eps, int step, const float* sumsq, float max_norm,
                      const float* grad_scale_mask, const int32_t* skip_flag, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Per-step scalars read ON THE DEVICE, so that a captured HIP graph of the whole training step
+ * (bin/train.py:84-88,119-126) can be replayed step after step: the values that change from one
+ * step to the next -- the RNG stream of the dropout masks, the annealed word-dropout rate
+ * (vae/enhance_syntax_vae.py:292 `step_unk_rate`), the KL weight (vae/base_vae.py:192-196),
+ * Adam's learning rate and bias corrections (utils/model_utils.py:195) -- live in a small device
+ * buffer that ONE launch per step rewrites (dssvae_set_words: the words travel BY VALUE in the
+ * kernel arguments, so the host array may be reused as soon as the call returns), and the *_dyn
+ * entry points below take device pointers into it beside the host values of their plain
+ * counterparts (NULL pointer = the host value alone, i.e. exactly the plain entry point).
+ * No reference counterpart for the mechanism; each *_dyn cites its plain twin's call site.
+ * ------------------------------------------------------------------------------------------- */
+#define DSSVAE_STEP_WORDS 128
+int dssvae_set_words(uint32_t* dst, const uint32_t* words_host, int n, void* stream);
+/* seed used = seed + (seed_base ? *seed_base : 0)  (64-bit wrap-around) */
+int dssvae_dropout_mask_dyn(float* mask, int64_t n, float p, uint64_t seed, const uint64_t* seed_base, void* stream);
+int dssvae_dropout_apply_dyn(const float* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_base, float* y,
+                             void* stream);
+/* rate used = rate_dev ? *rate_dev : rate */
+int dssvae_unk_replace_dyn(const int64_t* ids, int64_t n, const float* rand, float rate, const float* rate_dev,
+                           uint64_t seed, const uint64_t* seed_base, int64_t sos, int64_t pad, int64_t eos,
+                           int64_t unk, int64_t* out, void* stream);
+/* coefficient used = coef[j*n_in + k] + (dyn ? coef_dyn[j*n_in + k] * *dyn : 0): the rows of the loss dictionary that
+ * carry the KL weight ('KL Item', 'ELBO', 'Loss') */
+int dssvae_weighted_sums_fwd_dyn(const float* const* in, const int32_t* len, int n_in, const float* coef,
+                                 const float* coef_dyn, const float* dyn, int n_out, float* out, void* stream);
+int dssvae_weighted_sums_bwd_dyn(float* const* din, const int32_t* len, int n_in, const float* coef,
+                                 const float* coef_dyn, const float* dyn, int n_out, const float* const* dout,
+                                 void* stream);
+/* hyper (device, 3 floats): lr, 1 - beta1^step, sqrt(1 - beta2^step) */
+int dssvae_adam_step_dyn(float* p, const float* g, float* m, float* v, int64_t n, const float* hyper, float beta1,
+                         float beta2, float eps, const float* sumsq, float max_norm, const int32_t* skip_flag,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Minibatches cut on the device from a dataset that was tensorised ONCE (train.bin as flat ids +
+ * offsets resident in HBM; replaces the per-step Python of utils/nn_funcs.py:143-174 `to_input_variable` /
+ * :122-129 `padding_input` / :43-47 `word2id` and structs/dataset.py:64-75):
+ *   flat_ids [sum of lengths] int64, offsets [n_examples + 1] int64, idx [B] int64 = the examples of the batch;
+ *   out [B, W] int64: row b = [sos] ids of example idx[b] [eos] pad..  (boundary = 1) or ids pad.. (boundary = 0),
+ *   cut at W; lengths_out [B] int32 (may be NULL) = the examples' own lengths (without boundary symbols).
+ * dssvae_keep_rows: the flattened [B, T] positions (b*T + t, t < min(lengths[b] + 1, T)) whose teacher-forced target
+ * is not <pad>, in order, into keep [n_keep] (n_keep known to the caller from the lengths; positions beyond the real
+ * count are filled with the last real position).  B <= 8192.
+ * ------------------------------------------------------------------------------------------- */
+int dssvae_batch_rows(const int64_t* flat_ids, const int64_t* offsets, const int64_t* idx, int B, int W, int boundary,
+                      int64_t sos, int64_t eos, int64_t pad, int64_t* out, int32_t* lengths_out, void* stream);
+int dssvae_keep_rows(const int32_t* lengths, int B, int T, int64_t* keep, int n_keep, void* stream);
 
 #ifdef __cplusplus
 }
