@@ -16,8 +16,16 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel of the step,
 live with HIP events on the stream they run on; `kernels` lists the other hot kernels the same way;
 `cpu_baseline` is the CPU oracle (oracle/, the restatement of the reference pinned by the golden
 vectors) timed on this box's host cores on a bounded sample of the same workload (N=1 only).
-`without_kernel_events` repeats the K steps without the per-kernel events after the timed region (they cost
-it ~1.5 %): reported beside `value`, which stays the instrumented region's.
+
+The timed region is the product's training step as `bin/train.py` runs it: `train.GraphedTrainer`, i.e. after two
+eager steps the whole iteration is one captured HIP graph, replayed once per step (`--no-graph`: eager launches).
+Event records cannot be read back from inside a replayed graph, so the per-kernel durations behind `roofline` /
+`kernels` come from a second pass over the same K steps, launched eagerly with the events on (`with_kernel_events`:
+its ms/step; `eager`: the same without events), right after the timed region.  `host_enqueue_ms_per_step` is the
+host's share of a timed step (every launch of the K steps enqueued, before the final sync), given for every pass.
+`driver`: sentences/s of `dss_vae_amd.bin.train.training()` itself -- files in the reference's formats, id cache,
+shuffled batches cut on the device, the same captured step -- over a synthetic `train.bin` of the same shape
+(`--mode driver`: BASELINE configs[2]'s 100 k sentences per epoch as the one JSON line).
 """
 import argparse
 import json
@@ -64,9 +72,14 @@ def parse():
     ap.add_argument("--tree-len", type=int, default=90)
     ap.add_argument("--variable-lengths", action="store_true")
     ap.add_argument("--stress", action="store_true", help="BASELINE configs[3]: hidden 1024, latent 256")
-    ap.add_argument("--mode", default="train", choices=["train", "generate"],
+    ap.add_argument("--mode", default="train", choices=["train", "generate", "driver"],
                     help="train = the headline metric; generate = BASELINE configs[4] (prior sampling + syntax "
-                         "transfer greedy decode), a secondary line")
+                         "transfer greedy decode), a secondary line; driver = bin/train.py's training() over a "
+                         "synthetic train.bin (BASELINE configs[2]: 100 k sentences per epoch)")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of the captured HIP graph")
+    ap.add_argument("--driver-sentences", type=int, default=None,
+                    help="size of the synthetic train.bin (default: 100000 in --mode driver, 16384 for the short "
+                         "driver leg of --mode train; 0 skips that leg)")
     ap.add_argument("--adv-train", action="store_true",
                     help="secondary: the 3-pass adversarial iteration (dis-syn step, dis-sem step, main step)")
     ap.add_argument("--gen-sentences", type=int, default=10000)
@@ -241,6 +254,62 @@ def generate_bench(a, model, vocab, margs, rank, world, margs_dict=None):
         print(json.dumps(line), flush=True)
 
 
+def driver_bench(a, margs_dict, rank, world, n_sentences, steps):
+    """sentences/s of bin/train.py's training() (the loop a user runs) over a synthetic train.bin of the workload's
+    shape: vocab.bin / train.bin / dev.bin in the reference's pickle formats, the id cache, shuffled batches cut on
+    the device, the captured step.  The clock starts after 6 iterations (model build, file loading, id conversion and
+    the graph capture are one-time costs) and stops, synchronised, after `steps` more."""
+    import shutil
+    import tempfile
+    from argparse import Namespace
+    import torch
+    import torch.distributed as dist
+    from dss_vae_amd import synthetic
+    from dss_vae_amd.bin.train import training
+    from dss_vae_amd.structs import Dataset
+    tmp = os.path.join(tempfile.gettempdir(), "dssvae_bench_%s" % os.environ.get("MASTER_PORT", str(os.getpid())))
+    t_files = time.perf_counter()
+    if rank == 0:
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        synthetic.vocab(a.vocab, a.tree_vocab).save(os.path.join(tmp, "vocab.bin"))
+        Dataset(synthetic.examples(n_sentences, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len,
+                                   fixed=not a.variable_lengths, seed=77)).save(os.path.join(tmp, "train.bin"))
+        Dataset(synthetic.examples(64, a.vocab, a.tree_vocab, src_len=a.src_len, tree_len=a.tree_len,
+                                   fixed=not a.variable_lengths, seed=78)).save(os.path.join(tmp, "dev.bin"))
+    if world > 1:
+        dist.barrier()
+    t_files = time.perf_counter() - t_files
+    skip = 6
+    per_epoch = (n_sentences + a.batch * world - 1) // (a.batch * world)
+    steps = min(steps, max(1, per_epoch - skip)) if steps else max(1, per_epoch - skip)
+    main_args = Namespace(train_file=os.path.join(tmp, "train.bin"), dev_file=os.path.join(tmp, "dev.bin"),
+                          vocab=os.path.join(tmp, "vocab.bin"), eval_lists=None, logdir=os.path.join(tmp, "logs"),
+                          model_dir=os.path.join(tmp, "models"), exp_name="bench", task_type=a.model, start_iter=6000,
+                          batch_size=a.batch, log_every=50, dev_every=10 ** 9, lr=0.0005, lr_decay=0.8, patience=8,
+                          clip_grad=5.0, reset_optimizer=False, mode="train", seed=0, bench_skip=skip)
+    import contextlib
+    t0 = time.perf_counter()
+    with contextlib.redirect_stdout(sys.stderr):   # the loop's progress lines: stdout carries the one JSON line only
+        out = training(main_args, Namespace(**margs_dict), max_iters=skip + steps)
+    wall = time.perf_counter() - t0
+    tm, runner = out["timed"], out["runner"]
+    dt = tm["seconds"]
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t[0].item())
+    res = {"sentences_per_s": world * tm["sentences"] / dt, "ms_per_step": 1e3 * dt / tm["steps"], "steps": tm["steps"],
+           "train_bin_sentences": n_sentences, "batch_per_gpu": a.batch,
+           "graph_replays": runner.replays, "eager_steps": runner.eager, "graphs_captured": runner.captures,
+           "one_time_s": {"synthetic_files_written": t_files, "training_call_minus_timed_steps": wall - tm["seconds"]}}
+    del out
+    torch.cuda.empty_cache()
+    if rank == 0:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -276,7 +345,7 @@ def main():
 
     from dss_vae_amd import ops, synthetic
     from dss_vae_amd.models import MODEL_CLS
-    from dss_vae_amd.train import FlatAdam, build_model_params_, train_iteration
+    from dss_vae_amd.train import FlatAdam, GraphedTrainer, build_model_params_, train_iteration
     from dss_vae_amd.vae.base_vae import DeviceBatch
 
     over = dict(synthetic.STRESS_OVERRIDES) if a.stress else {}
@@ -284,6 +353,26 @@ def main():
         over["tgt_wd"] = False  # the reference's tgt_wd path of VanillaVAE does not run (vanilla_vae.py:112)
     margs = synthetic.model_args(model_select=a.model, task_type=a.model, **over)
     margs_dict = dict(vars(margs))
+    if a.mode == "driver":
+        n_sent = 100000 if a.driver_sentences is None else a.driver_sentences
+        res = driver_bench(a, margs_dict, rank, world, n_sent, 0)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "train sentences/sec (fwd+bwd) DSS-VAE", "value": res["sentences_per_s"],
+                "unit": "sentences/s", "n_gpus": world, "steps": res["steps"], "warmup": 6,
+                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32", "data": "synthetic",
+                "config": {"workload": "BASELINE configs[2]: bin/train.py training() over a synthetic train.bin of %d "
+                                       "sentences (%s, vocab %d, tree vocab %d, src len %d, tree len %d%s), batch %d "
+                                       "per GPU, one epoch minus the first 6 iterations"
+                                       % (n_sent, a.model, a.vocab, a.tree_vocab, a.src_len, a.tree_len,
+                                          " (variable)" if a.variable_lengths else " (fixed)", a.batch),
+                           "global_batch": a.batch * world, "parallelism": "dp%d" % world},
+                "driver": res}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     vocab = synthetic.vocab(a.vocab, a.tree_vocab)
     model = MODEL_CLS[a.model](args=margs, vocab=vocab)
     build_model_params_(model, seed=0)
@@ -304,42 +393,57 @@ def main():
         torch.cuda.synchronize()
 
     it = 6000
+    runner = GraphedTrainer(model, opt, a.adv_train, a.adv_train, enabled=not a.no_graph)
     for _ in range(a.warmup):
         it += 1
-        train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
+        runner(batch, it)
+    extra_warmup = 0
+    while runner.enabled and runner.captures == 0 and extra_warmup < 4:
+        # the step is captured at its third call: fewer warm-up steps than that are topped up, untimed
+        it += 1
+        extra_warmup += 1
+        runner(batch, it)
     sync()
-    timer = None if a.no_kernel_events else ops.KernelTimer()
-    ops.PROFILE = timer
+    ops.check_persistent_errors()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         it += 1
-        ret = train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
+        ret = runner(batch, it)
     host_dt = time.perf_counter() - t0   # every launch of the K steps is enqueued: the host's share of a step
     sync()
     dt = time.perf_counter() - t0
-    ops.PROFILE = None
+    replays_timed = runner.replays
     ops.check_persistent_errors()
-    # The per-kernel events are part of the timed region above (the roofline is measured live over it) and cost it
-    # ~1.5 %: the same K steps once more without them, reported beside `value`, never instead of it.
-    dt_plain = None
-    if timer is not None:
+
+    def eager_pass(with_events):
+        nonlocal it
+        tm = ops.KernelTimer() if with_events else None
+        ops.PROFILE = tm
         sync()
         t1 = time.perf_counter()
         for _ in range(a.steps):
             it += 1
             train_iteration(model, opt, batch, it, a.adv_train, a.adv_train)
+        h = time.perf_counter() - t1
         sync()
-        dt_plain = time.perf_counter() - t1
+        d = time.perf_counter() - t1
+        ops.PROFILE = None
         ops.check_persistent_errors()
+        return tm, d, h
+
+    # the same K steps launched eagerly: with the per-kernel events (the live roofline measurement), and without
+    timer, dt_events, host_events = eager_pass(True) if not a.no_kernel_events else (None, None, None)
+    _, dt_plain, host_plain = eager_pass(False) if (runner.enabled and not a.no_kernel_events) else (None, None, None)
     if a.shapes:
         sys.stderr.write("gradients adopted in place %d, copied into the flat buffer %d (all steps)\n"
                          % (opt.adopted, opt.copied))
     loss = float(torch.mean(ret["Loss"]).item())
     if world > 1:
-        t = torch.tensor([dt, dt_plain or 0.0], device="cuda", dtype=torch.float64)
+        t = torch.tensor([dt, dt_plain or 0.0, dt_events or 0.0], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0].item())
         dt_plain = float(t[1].item()) if dt_plain is not None else None
+        dt_events = float(t[2].item()) if dt_events is not None else None
 
     out = None
     if rank == 0:
@@ -357,10 +461,18 @@ def main():
                                       margs.enc_hidden_dim, margs.latent_size),
                        "global_batch": a.batch * world, "parallelism": "dp%d" % world, "params": n_params},
             "final_loss": loss,
+            "launch": {"mode": "hip_graph" if replays_timed else "eager", "graph_replays": replays_timed,
+                       "eager_steps": runner.eager, "graphs_captured": runner.captures,
+                       "extra_warmup": extra_warmup},
         }
+        if dt_events:
+            out["with_kernel_events"] = {"ms_per_step": 1e3 * dt_events / a.steps,
+                                         "value": a.batch * world * a.steps / dt_events, "steps": a.steps,
+                                         "host_enqueue_ms_per_step": 1e3 * host_events / a.steps}
         if dt_plain:
-            out["without_kernel_events"] = {"ms_per_step": 1e3 * dt_plain / a.steps,
-                                            "value": a.batch * world * a.steps / dt_plain, "steps": a.steps}
+            out["eager"] = {"ms_per_step": 1e3 * dt_plain / a.steps,
+                            "value": a.batch * world * a.steps / dt_plain, "steps": a.steps,
+                            "host_enqueue_ms_per_step": 1e3 * host_plain / a.steps}
         if timer is not None:
             summ = timer.summary()
             if a.shapes:
@@ -396,6 +508,12 @@ def main():
                 out["kernels"] = kernels[1:]
                 out["timed_kernel_ms_per_step"] = sum(k["ms_per_step"] for k in kernels)
                 out["traffic_source"] = traffic_src
+    n_drv = 16384 if a.driver_sentences is None else a.driver_sentences
+    if n_drv and not a.adv_train and not a.stress and world == 1:
+        del runner
+        drv = driver_bench(a, margs_dict, rank, world, n_drv, 40)
+        if rank == 0:
+            out["driver"] = drv
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -19,8 +19,9 @@ import torch.distributed as dist
 
 from .. import ops
 from ..metrics import get_evaluator
-from ..parallel import shard_examples, world_size
-from ..train import train_iteration
+from ..parallel import world_size
+from ..structs.id_cache import IdCache
+from ..train import GraphedTrainer
 from ..utils.config_funcs import dict_to_args, yaml_to_dict
 from ..utils.model_utils import build_model, get_lr_schedule, get_model_info, load_data, update_tracker
 
@@ -57,6 +58,9 @@ def training(main_args, model_args, model=None, max_iters=None):
     model, optimizer, vocab = build_model(main_args=main_args, model_args=model_args, model=model,
                                           seed=getattr(main_args, "seed", None))
     train_set, dev_set = load_data(main_args)
+    # train.bin as flat ids + offsets, converted once (cached beside the pickle by rank 0) and resident in HBM: a
+    # step's batch is a list of example indices, cut into padded id matrices on the device (structs/id_cache.py)
+    cache = IdCache.for_file(main_args.train_file, train_set.examples, vocab, write=rank == 0).cuda()
     if world > 1:
         # replicas start from rank 0's parameters whatever the ranks' seeds were, and draw different noise
         dist.broadcast(optimizer.flat, 0)
@@ -82,6 +86,10 @@ def training(main_args, model_args, model=None, max_iters=None):
     if adv_training:  # hyper_init, bin/train.py:76-82
         adv_syn = (model_args.adv_syn + model_args.infer_weight * model_args.inf_sem) > 0.0
         adv_sem = (model_args.adv_sem + model_args.infer_weight * model_args.inf_syn) > 0.0
+    # the iteration behind a HIP graph per batch shape (train.GraphedTrainer; DSSVAE_GRAPH=0: always eager)
+    run_iteration = GraphedTrainer(model, optimizer, adv_syn, adv_sem)
+    bench_skip = getattr(main_args, "bench_skip", None)   # bench.py --mode driver: start a clock after this many steps
+    timed = None
 
     while True:
         epoch += 1
@@ -92,14 +100,16 @@ def training(main_args, model_args, model=None, max_iters=None):
             seed_t = torch.tensor([int(np.random.randint(0, 2 ** 31 - 1))], device="cuda", dtype=torch.int64)
             dist.broadcast(seed_t, 0)
             rng = np.random.RandomState(int(seed_t.item()))
-        for global_batch in train_set.batch_iter(batch_size=main_args.batch_size * world, shuffle=True, rng=rng):
-            if len(global_batch) < world:
+        for n_global, batch_examples in cache.batch_iter(main_args.batch_size, shuffle=True, rng=rng, rank=rank,
+                                                         world=world):
+            if n_global < world:
                 continue  # every rank must take part in the step's collectives: all ranks drop the same tail
-            batch_examples = shard_examples(global_batch, rank, world) if world > 1 else global_batch
+            if bench_skip is not None and train_iter - main_args.start_iter == bench_skip:
+                torch.cuda.synchronize()
+                timed = [time.perf_counter(), train_iter, train_nums]
             train_iter += 1
             train_nums += len(batch_examples)
-            batch_ret = train_iteration(model, optimizer, batch_examples, train_iter, adv_syn, adv_sem,
-                                        global_batch=len(global_batch))
+            batch_ret = run_iteration(batch_examples, train_iter, global_batch=n_global)
             batch_loss = batch_ret["Loss"]
             train_log_dict = update_tracker(batch_ret, train_log_dict)
             if train_iter % main_args.log_every == 0:
@@ -155,8 +165,13 @@ def training(main_args, model_args, model=None, max_iters=None):
                     optimizer.steps = [int(x) for x in st.tolist()]
                 model.train()
             if max_iters is not None and train_iter - main_args.start_iter >= max_iters:
-                return {"model": model, "optimizer": optimizer, "train_iter": train_iter, "history": history_scores,
-                        "model_file": model_file, "log_dir": dir_ret["log_dir"]}
+                out = {"model": model, "optimizer": optimizer, "train_iter": train_iter, "history": history_scores,
+                       "model_file": model_file, "log_dir": dir_ret["log_dir"], "runner": run_iteration}
+                if timed is not None:
+                    torch.cuda.synchronize()
+                    out["timed"] = {"seconds": time.perf_counter() - timed[0], "steps": train_iter - timed[1],
+                                    "sentences": train_nums - timed[2]}
+                return out
         print("\r[Epoch %d] epoch elapsed %ds" % (epoch, time.time() - epoch_begin), file=sys.stdout)
 
 
