@@ -222,16 +222,20 @@ class FlatAdam(object):
         """in front of a replay of a captured step: (lr, 1 - beta1^t, sqrt(1 - beta2^t)) of every Adam range of the
         graph into its per-step slots, and the step counts advanced as step() would.  -> False when the members of a
         range no longer share one step count (eager steps of another kind ran in between): the graph is stale."""
-        for slot, members in dyn.adam:
-            if len(set(self.steps[i] for i in members)) != 1:
+        steps = list(self.steps)
+        plan = []
+        for slot, members in dyn.adam:  # in the order the captured step() calls ran: a parameter may be in several
+            if len(set(steps[i] for i in members)) != 1:
                 return False
-        for slot, members in dyn.adam:
-            st = self.steps[members[0]] + 1
+            st = steps[members[0]] + 1
+            plan.append((slot, st))
+            for i in members:
+                steps[i] = st
+        for slot, st in plan:
             dyn.set_float(slot, self.lr)
             dyn.set_float(slot + 1, 1.0 - self.betas[0] ** st)
             dyn.set_float(slot + 2, (1.0 - self.betas[1] ** st) ** 0.5)
-            for i in members:
-                self.steps[i] += 1
+        self.steps = steps
         return True
 
     def grad_norm(self):
