@@ -118,3 +118,65 @@ def test_rccl_one_rank_group_runs_the_whole_schedule():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dp_world1_probe.py")], capture_output=True,
                          text=True, timeout=170)
     assert out.returncode == 0 and out.stdout.strip().endswith("ok"), (out.stdout[-2000:], out.stderr[-2000:])
+
+
+def _graph_worker(rank, world, port, q):
+    import faulthandler
+    faulthandler.dump_traceback_later(120, exit=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dss_vae_amd import ops
+        from dss_vae_amd.train import FlatAdam, GraphedTrainer
+        from dss_vae_amd.vae.base_vae import DeviceBatch
+        ops.CHECK_UNIFORM_UPSTREAM = False
+        results = []
+        for graph in (False, True):
+            model, exs, _ = _setup()
+            opt = FlatAdam(model, bucket_mb=0.01)
+            batch = DeviceBatch(exs[rank::world], model.vocab)
+            torch.manual_seed(100 + rank)
+            runner = GraphedTrainer(model, opt, enabled=graph)
+            losses = [float(runner(batch, 6000 + s, global_batch=B)["Loss"]) for s in range(8)]
+            ops.check_persistent_errors()
+            if graph:
+                assert runner.captures == 1 and runner.replays == 5 and len(runner.graphs[next(iter(runner.graphs))]["graphs"]) == 2
+            results.append((losses, opt.flat.clone()))
+            # replicas hold the same parameters: every rank applied the same averaged gradients
+            mine = opt.flat.double().cpu()
+            other = mine.clone()
+            dist.broadcast(other, 0)
+            assert torch.equal(mine, other) or (mine - other).abs().max().item() == 0.0
+        (le, pe), (lg, pg) = results
+        for a, b in zip(le, lg):
+            assert abs(a - b) <= 2e-5 * abs(a), (le, lg)
+        assert (pe - pg).abs().max().item() <= 2e-4 * pe.abs().max().item()
+        dist.barrier()
+        faulthandler.cancel_dump_traceback_later()
+        q.put((rank, "ok"))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, "FAIL %r" % (e,)))
+        raise
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_captured_step_equals_two_rank_eager_step():
+    """data parallel behind HIP graphs (train.GraphedTrainer's split mode: [zero_grad + forward + backward] |
+    eager all-reduce of the live buckets | [norm + clip + Adam]) against the hook-driven eager schedule on the same
+    two ranks: same losses over 8 steps (5 of them replays), same parameters, replicas identical"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=170) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
