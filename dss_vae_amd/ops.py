@@ -775,6 +775,12 @@ class _LinearCEFn(Function):
                 if Kw > K:
                     parts.append(_ones_col(M, dev))
                 xcat = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+                if fuse and (xcat.stride(0) % 4 != 0 or xcat.data_ptr() % 16 != 0):
+                    # the wgrad's right operand went in as the caller's own view (no concatenation made a fresh one):
+                    # the staged-slab GEMM wants 16-byte rows
+                    xcat = xcat.contiguous()
+                    if xcat.stride(0) % 4 != 0:
+                        xcat = torch.nn.functional.pad(xcat, (0, 4 - xcat.size(1) % 4))[:, :Kw]
             main = torch.cuda.current_stream()
             streams = [main] + [_side_stream(dev, i) for i in range(n_str - 1)]
             for st in streams[1:]:

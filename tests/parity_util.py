@@ -94,6 +94,18 @@ def rel_err(a, b):
     return ((a - b).abs().max().item() / denom) if b.numel() else 0.0
 
 
+def grad_excess(got, want, rtol=2e-3, atol_frac=1e-6):
+    """element-wise bar for a gradient tensor: max over elements of |got - want| / (atol + rtol |want|) with atol =
+    atol_frac x max|want| (<= 1 passes, as torch.allclose); a tensor-max-normalised error lets a small-magnitude row be
+    wrong by more than its own size"""
+    a = torch.as_tensor(got).detach().double().cpu()
+    b = torch.as_tensor(want).detach().double().cpu()
+    if not b.numel():
+        return 0.0
+    atol = atol_frac * max(b.abs().max().item(), 1e-30)
+    return ((a - b).abs() / (atol + rtol * b.abs())).max().item()
+
+
 def compare_loss_dicts(got, want, rtol=1e-4, what=""):
     """north_star bar: per-term losses within 1e-4 relative in fp32."""
     assert set(got) == set(want), (what, sorted(got), sorted(want))

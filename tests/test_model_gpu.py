@@ -4,14 +4,21 @@
 Bar (north_star): per-term losses within 1e-4 relative in fp32; identical greedy decodes."""
 import copy
 
+import os
+
 import pytest
 import torch
 
 import oracle
 from conftest import CASES, golden_args, load_golden
-from parity_util import (build_pair, compare_loss_dicts, make_args, make_examples, product_examples, rel_err, words)
+from parity_util import (build_pair, compare_loss_dicts, grad_excess, make_args, make_examples, product_examples, rel_err,
+                         words)
 
 pytestmark = pytest.mark.gpu
+# absolute part of the element-wise gradient bar, as a fraction of the tensor's largest element: fp32 sums of a few
+# hundred to a few thousand terms taken in another order than the reference's differ by about 1e-7 x the sum of the
+# terms' magnitudes, which an element that is itself a near-cancellation does not shrink with
+GRAD_ATOL = float(os.environ.get("DSSVAE_TEST_GRAD_ATOL", "1e-6"))
 
 
 def examples(g, key="examples"):
@@ -126,6 +133,8 @@ def test_golden_train_losses_grads_and_discriminator(case):
         for n, gg in g[key + "_grads"].items():
             assert named[n].grad is not None, n
             assert rel_err(named[n].grad, gg) < 2e-3, (key, n, rel_err(named[n].grad, gg))
+            # ... and element by element: |d| <= 2e-3 |want| + GRAD_ATOL x max|want| (torch.allclose's form)
+            assert grad_excess(named[n].grad, gg, 2e-3, GRAD_ATOL) <= 1.0, (key, n, grad_excess(named[n].grad, gg, 2e-3, GRAD_ATOL))
             gn += float((named[n].grad.double() ** 2).sum())
         for n in g[key + "_nograd"]:
             assert named[n].grad is None, n
@@ -192,6 +201,7 @@ def test_oracle_parity_default_dims(model, fixed):
             assert p.grad is None, n
             continue
         assert rel_err(p.grad, og[n].grad) < 5e-3, (n, rel_err(p.grad, og[n].grad))
+        assert grad_excess(p.grad, og[n].grad, 5e-3, GRAD_ATOL) <= 1.0, (n, grad_excess(p.grad, og[n].grad, 5e-3, GRAD_ATOL))
         sq_ref += float((og[n].grad.double() ** 2).sum())
         sq_hip += float((p.grad.double() ** 2).sum())
     assert abs(sq_hip ** 0.5 - sq_ref ** 0.5) / sq_ref ** 0.5 < 1e-4

@@ -245,3 +245,57 @@ def test_three_pass_adversarial_iteration_matches_oracle(model):
     for k in osd:
         a, b = psd[k].cpu().double(), osd[k].double()
         assert torch.allclose(a, b, rtol=1e-4, atol=4e-5), (k, (a - b).abs().max().item())
+
+
+def test_dev_evaluator_matches_oracle(tmp_path):
+    """SURVEY 8f N3 at the oracle's level (metrics/syntax_vae_evaluator.py:114-161, utils/model_utils.py:16-30):
+    `SyntaxEvaluator()` on a small ragged dev set -- every tracked loss term equals the oracle's `get_loss` terms of
+    the same batches (each batch's mean, concatenated in batch order, as `update_tracker` does), `pred.txt` equals
+    the oracle's greedy words sentence by sentence, and BLEU equals metrics/bleu.py applied to those words."""
+    from dss_vae_amd.metrics import bleu
+    from dss_vae_amd.metrics.evaluation import batchify_examples
+    from dss_vae_amd.metrics.evaluator import SyntaxEvaluator
+    n_src, n_tgt = 120, 30
+    args = make_args(eval_bs=5, dev_item="ELBO", x0=50, **TINY)
+    om, pm = build_pair("SyntaxVAE2", args, n_src, n_tgt, seed=11, train=False)
+    o_exs = make_examples(13, n_src, n_tgt, src_len=9, tree_len=27, fixed=False, seed=21)
+    import random
+    random.Random(3).shuffle(o_exs)                      # a dev file is not sorted by length
+    p_exs = product_examples(o_exs)
+    ev = SyntaxEvaluator(pm, p_exs, sort_key="src", eval_tgt="src", batch_size=5, out_dir=str(tmp_path / "out"),
+                         write_down=True)
+    out = ev()
+    # ---- ELBO tracker
+    batches, _ = batchify_examples(o_exs, batch_size=5, sort=False)
+    assert [len(b) for b in batches] == [5, 5, 3]
+    want = {}
+    with torch.no_grad():
+        for b in batches:
+            for k, v in om.get_loss(b, 2 * args.x0).items():
+                if isinstance(v, torch.Tensor):
+                    want.setdefault(k, []).append(float(v.mean()))
+                else:
+                    want[k] = want.get(k, 0.0) + v
+    for k, w in want.items():
+        got = out[k]
+        if isinstance(w, list):
+            assert isinstance(got, torch.Tensor) and got.numel() == 3, k
+            for a, b in zip(got.tolist(), w):
+                assert abs(a - b) <= 1e-4 * max(abs(b), 1e-6), (k, got.tolist(), w)
+        else:
+            assert abs(got - w) <= 1e-6 * max(abs(w), 1.0), k
+    assert out[ev.score_item] is out["ELBO"]
+    scores = dict(l.split(":") for l in open(os.path.join(str(tmp_path / "out"), "vae-elbo.score")).read().splitlines())
+    assert abs(float(scores["ELBO"]) - sum(want["ELBO"]) / 3) <= 1e-4 * abs(sum(want["ELBO"]) / 3)
+    # ---- reconstruction: greedy words and BLEU
+    rec = os.path.join(str(tmp_path / "out"), "vae-reconsturct")
+    pred = open(os.path.join(rec, "pred.txt")).read().splitlines()
+    gold = open(os.path.join(rec, "gold.txt")).read().splitlines()
+    assert gold == [" ".join(e.src) for e in o_exs]
+    o_pred = []
+    with torch.no_grad():
+        for e in o_exs:
+            toks = om.predict_tokens([e])
+            o_pred.append(" ".join(oracle.ids_to_words(toks[:, 0].tolist(), om.vocab.src)))
+    assert pred == o_pred
+    assert abs(out["BLEU"] - bleu.evaluate_lines(o_pred, [gold])) < 1e-9
