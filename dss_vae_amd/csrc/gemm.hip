@@ -62,6 +62,7 @@ template <> struct VecT<1> { typedef float T; static __device__ __forceinline__ 
 template <bool TRANS, int VW, int R, bool XF = false>
 struct Stager {
     static_assert(!XF || VW == 4, "the dlogits transform is written for 16-byte granules");
+    static constexpr bool MASK_FREE = false;
     static constexpr bool VEC = VW > 1;
     typedef typename VecT<VW>::T V;
     static constexpr int NV = R * BK / (NTHREADS * (VEC ? VW : 4));  // granules per thread (VEC)
@@ -127,6 +128,9 @@ struct Stager {
 
     // per-tile scalars of the load (k range check, panel choice); resets okmask
     __device__ __forceinline__ void begin_load(int k0) {
+#ifdef GEMM_DEV_SAMEK    // development build: every k-tile loads the first one again (cache hits; results are garbage)
+        k0 = 0;
+#endif
         if (!TRANS) {
             const int k = k0 + (VEC ? VW * (int)(threadIdx.x % TPR) : (int)(threadIdx.x % BK));
             const bool ok = k < K;
@@ -141,6 +145,9 @@ struct Stager {
     }
 
     __device__ __forceinline__ void load_part(int part) {
+#ifdef GEMM_DEV_NOLOAD   // development build: the mainloop without its global loads (results are garbage)
+        return;
+#endif
         if (!TRANS) {
             if (VEC) {
 #pragma unroll
@@ -203,6 +210,9 @@ struct Stager {
 #pragma unroll
         for (int part = 0; part < 4; ++part) load_part(part);
     }
+    // (the interface of FastStager: this stager masks every tile the same way)
+    template <bool TAIL> __device__ __forceinline__ void load_part(int part) { load_part(part); }
+    template <bool TAIL> __device__ __forceinline__ void store_part(float* img, int part) const { store_part(img, part); }
 
     // XF: the staged granules of one part become dlogits in place (before store_part writes them to LDS)
     __device__ __forceinline__ void xform_part(int part) {
@@ -214,6 +224,16 @@ struct Stager {
     }
 
     __device__ __forceinline__ void store_part(float* img, int part) const {
+#ifdef GEMM_DEV_NOSTORE  // development build: the mainloop without its LDS staging stores (results are garbage)
+#ifdef GEMM_DEV_KEEPLOAD  // ... but with the global loads kept alive
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part)) asm volatile("" ::"v"(v[i]));
+        }
+#endif
+        return;
+#endif
         if (!TRANS) {
             if (VEC) {
 #pragma unroll
@@ -255,6 +275,156 @@ struct Stager {
     }
 };
 
+// ---- the same for 16-byte granules (VW = 4), with NO vector-ALU work per k-tile ---------------------------------
+// v_mfma_f32_32x32x2_f32 runs on the fp32 vector ALUs (its rate IS the fp32 vector rate), so every VALU instruction
+// any wave of the SIMD issues takes its cycles away from the MFMAs: measured with tools/probes/mfma_valu.hip, a
+// v_add_f32 / v_cndmask beside a bare MFMA loop costs ~5 cycles of matrix time at one wave per SIMD (~3 at two), a
+// v_exp_f32 ~9 -- against 64 cycles per MFMA.  The generic stager above spends ~60 VALU instructions per k-tile on
+// addresses (64-bit pointer arithmetic per granule), panel selection and the k-tail select: the same mainloop without
+// its loads runs at 150 TFLOP/s, with them at 124 (4096^3; tools/gemm_variants.py).  Here the per-tile part of every
+// address is UNIFORM -- the tile's first k, times the leading dimension for a transposed operand -- and lives in
+// scalar registers; a thread keeps one 32-bit byte offset per granule for the whole tile loop (global_load with an
+// SGPR base), the LDS addresses are a per-thread constant plus immediates, and the k-tail costs a scalar branch
+// that only the last k-tile of a product takes.  Host-checked (fast_ok): one panel, no row gather, offsets < 4 GiB.
+template <bool TRANS, int R, bool XF = false>
+struct FastStager {
+    static constexpr int NV = R * BK / (NTHREADS * 4);   // 16-byte granules per thread (R = 128: 4, R = 64: 2)
+    static constexpr int TPR = BK / 4, RPP = NTHREADS / TPR;      // k-contiguous image: 8 threads per row, 32 rows per pass
+    static constexpr int TPK = R / 4, KSTEP = NTHREADS / TPK;     // transposed image: threads per k row, k rows per pass
+    static constexpr bool MASK_FREE = true;   // load_part<false> / store_part<false> keep no per-tile state
+    static_assert(!XF || (NV == 4 && (!TRANS || KSTEP * NV == BK)), "the dlogits stagers are written for 128-row tiles");
+    float4 v[NV];
+    float ri[XF ? NV : 1];    // l2 of the slab rows of the staged granules (XF)
+    uint32_t off[NV];         // byte offset of granule i from the tile's base address
+    uint32_t st;              // float offset of granule 0 in the LDS image
+    const float* p; const float* xf;
+    int64_t ld;
+    int K, lk0;
+    bool xf_vec;              // uniform
+    unsigned okmask;          // set by load_part<true>: which granules hold in-range k
+
+    static __device__ __forceinline__ int krow(int i) {
+        return XF ? NV * (int)(threadIdx.x / TPK) + i : (int)(threadIdx.x / TPK) + KSTEP * i;
+    }
+    static constexpr __host__ __device__ bool in_part(int i, int part) { return (i * 4) / NV == part; }
+
+    __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int, const float*, int64_t, const int64_t*,
+                                         int Rtot, int r0, int K_, const float* xf_ = nullptr) {
+        p = p1_; ld = ld1_; K = K_; xf = xf_; okmask = ~0u; lk0 = 0;
+        xf_vec = (reinterpret_cast<uintptr_t>(xf_) & 15u) == 0;
+        if (!TRANS) {
+            st = (threadIdx.x / TPR) * LDK + 4 * (threadIdx.x % TPR);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const int r = min(r0 + (int)(threadIdx.x / TPR) + RPP * i, Rtot - 1);
+                off[i] = (uint32_t)(((int64_t)r * ld + 4 * (int)(threadIdx.x % TPR)) * 4);
+                if (XF) ri[i] = xf[r];   // the slab rows of this thread's granules never change
+            }
+        } else {
+            const int rv = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
+            st = krow(0) * (R + 4) + 4 * (threadIdx.x % TPK);
+#pragma unroll
+            for (int i = 0; i < NV; ++i) off[i] = (uint32_t)(((int64_t)krow(i) * ld + rv) * 4);
+        }
+    }
+
+    __device__ __forceinline__ void begin_load(int k0) { lk0 = k0; }
+
+    // TAIL = false: the tile is entirely in range (k0 + 32 <= K): scalar base + per-thread 32-bit offsets, nothing else.
+    // TAIL = true: any tile; out-of-range granules read an address that is certainly valid (k = 0 of their row / k row
+    // 0 of their column) and are zeroed when they are written to LDS.  Only the last three k-tiles of a product whose
+    // K is not a multiple of 32 (and the prologue) run the TAIL code.
+    template <bool TAIL>
+    __device__ __forceinline__ void load_part(int part) {
+#ifdef GEMM_DEV_NOLOAD
+        return;
+#endif
+        const char* base = reinterpret_cast<const char*>(TRANS ? p + (int64_t)lk0 * ld : p + lk0);
+        if constexpr (!TAIL) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part)) v[i] = *reinterpret_cast<const float4*>(base + off[i]);
+            if constexpr (XF && TRANS) {
+                if (part == 3) {   // (behind the last transform of the tile whose records these registers still hold)
+                    if (xf_vec) {
+                        const float4 q = *reinterpret_cast<const float4*>(
+                            reinterpret_cast<const char*>(xf + lk0) + 16u * (uint32_t)(threadIdx.x / TPK));
+                        ri[0] = q.x; ri[1] = q.y; ri[2] = q.z; ri[3] = q.w;
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NV; ++i) ri[i] = xf[lk0 + krow(i)];
+                    }
+                }
+            }
+        } else if constexpr (!TRANS) {
+            const uint32_t kc = 4 * (threadIdx.x % TPR);
+            const bool ok = lk0 + (int)kc < K;
+            okmask = ok ? ~0u : 0u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part))
+                    v[i] = *reinterpret_cast<const float4*>(ok ? base + off[i] : reinterpret_cast<const char*>(p) + (off[i] - 4 * kc));
+        } else {
+            if (part == 0) okmask = 0u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part)) {
+                    const bool ok = lk0 + krow(i) < K;
+                    okmask |= ok ? (1u << i) : 0u;
+                    v[i] = *reinterpret_cast<const float4*>(
+                        ok ? base + off[i] : reinterpret_cast<const char*>(p) + (off[i] - (uint32_t)((int64_t)krow(i) * ld * 4)));
+                }
+            if constexpr (XF) {
+                if (part == 0) {
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) ri[i] = xf[min(lk0 + krow(i), K - 1)];
+                }
+            }
+        }
+    }
+
+    __device__ __forceinline__ void load(int k0) {   // (prologue: any tile)
+        begin_load(k0);
+#pragma unroll
+        for (int part = 0; part < 4; ++part) load_part<true>(part);
+    }
+
+    __device__ __forceinline__ void xform_part(int part) {
+        if constexpr (XF) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i)
+                if (in_part(i, part)) v[i] = Stager<TRANS, 4, R, true>::dlogits(v[i], ri[i]);
+        }
+    }
+
+    // TAIL: the registers were filled by load_part<true> (okmask is valid)
+    template <bool TAIL>
+    __device__ __forceinline__ void store_part(float* img, int part) const {
+#ifdef GEMM_DEV_NOSTORE
+        return;
+#endif
+        constexpr int ISTRIDE = !TRANS ? RPP * LDK : (XF ? (R + 4) : KSTEP * (R + 4));
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+            if (in_part(i, part)) {
+                if constexpr (!TAIL) {
+                    *reinterpret_cast<float4*>(img + st + i * ISTRIDE) = v[i];
+                } else {
+                    *reinterpret_cast<float4*>(img + st + i * ISTRIDE) =
+                        ((okmask >> (TRANS ? i : 0)) & 1u) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+    }
+
+    __device__ __forceinline__ void store(float* img) const {   // (prologue)
+#pragma unroll
+        for (int part = 0; part < 4; ++part) store_part<true>(img, part);
+    }
+};
+
+template <bool TRANS, int VW, int R, bool XF> struct StagerOf { typedef Stager<TRANS, VW, R, XF> T; };
+template <bool TRANS, int R, bool XF> struct StagerOf<TRANS, 4, R, XF> { typedef FastStager<TRANS, R, XF> T; };
+
 // fragment of one 32-row MFMA tile for group g: f[j] multiplies k = 8g + 4h + j
 template <bool TRANS, int R>
 __device__ __forceinline__ void read_frag(float (&f)[4], const float* img, int row, int g, int h) {
@@ -268,12 +438,86 @@ __device__ __forceinline__ void read_frag(float (&f)[4], const float* img, int r
     }
 }
 
+// ---- one k-tile of the rotated software pipeline; CUR (which LDS buffer holds the tile) is a template parameter so
+// that every LDS address of the tile is a per-thread constant plus an immediate ------------------------------------
+template <bool TA, bool TB, int WM, int WN, bool XF, int CUR, bool TAIL, typename SA, typename SB>
+__device__ __forceinline__ void k_tile(SA& sa, SB& sb, float* As, float* Bs, int arow, int brow, int h, bool more, int k2,
+                                       float (&fa)[2][WM][4], float (&fb)[2][WN][4], f32x16 (&acc)[WM][WN]) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    constexpr int AF = img_floats(TA, BM), BF = img_floats(TB, BN);
+    constexpr int NG = BK / 8;
+    // The loads of tile kt + 2 overwrite the registers the stores of tile kt + 1 read.  The mask-free stagers load part jj
+    // right behind its store, in the same sub-step of group 0: a group of MFMAs more between a load and its use than
+    // from group 1, where the masking code has to wait (its per-tile mask is shared by the four parts).
+    constexpr int G_STORE = 0, G_LOAD = (!TAIL && SA::MASK_FREE && SB::MASK_FREE) ? 0 : 1;
+    const float* Ab = As + CUR * AF;
+    const float* Bb = Bs + CUR * BF;
+    float* An = As + (CUR ^ 1) * AF;
+    float* Bn = Bs + (CUR ^ 1) * BF;
+#pragma unroll
+    for (int g = 0; g < NG - 1; ++g) {
+        const int c = g & 1, n = c ^ 1;
+#pragma unroll
+        for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+#pragma unroll
+            for (int i = 0; i < WM; ++i)
+#pragma unroll
+                for (int j = 0; j < WN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
+            if (g == G_STORE) {
+                sa.xform_part(jj);
+                sa.template store_part<TAIL>(An, jj);
+                sb.template store_part<TAIL>(Bn, jj);
+                if constexpr (XF) {
+                    // one granule's transform (4 x {v_fma, v_exp}) rides between this sub-step's MFMAs instead of
+                    // queueing behind the last one
+#pragma unroll
+                    for (int q = 0; q < WM * WN; ++q) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, (8 + WM * WN - 1) / (WM * WN), 0);  // VALU
+                    }
+                }
+            }
+            if (g == G_LOAD) {
+                if (jj == 0) { sa.begin_load(k2); sb.begin_load(k2); }
+                sa.template load_part<TAIL>(jj);
+                sb.template load_part<TAIL>(jj);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // keep the sub-steps apart: MFMAs, then their share of staging
+        }
+    }
+#ifndef GEMM_DEV_NOBARRIER  // development build: no workgroup barrier per k-tile (racy; results are garbage)
+    __syncthreads();
+#endif
+    constexpr int cl = (NG - 1) & 1, nl = cl ^ 1;  // NG is even: the next tile's group 0 lands in slot 0
+    static_assert(nl == 0, "fragment slot rotation assumes an even number of groups per k-tile");
+    if (more) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[nl][i], An, arow + 32 * i, 0, h);
+#pragma unroll
+        for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[nl][j], Bn, brow + 32 * j, 0, h);
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+#pragma unroll
+            for (int j = 0; j < WN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cl][i][jj], fb[cl][j][jj], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- one (64*WM) x (64*WN) output tile over k-tiles [kt0, kt1) -----------------------------------
 template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
 __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M, int N, int K, int m0, int n0,
                                               int kt0, int kt1, float* lds, f32x16 (&acc)[WM][WN]) {
     constexpr int BM = 64 * WM, BN = 64 * WN;
-    constexpr int AF = img_floats(TA, BM), BF = img_floats(TB, BN);
+    constexpr int AF = img_floats(TA, BM);
     float* As = lds;            // [2][AF]
     float* Bs = lds + 2 * AF;   // [2][BF]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -286,23 +530,22 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    Stager<TA, VW, BM, XF> sa;
-    Stager<TB, VW, BN> sb;
+    typename StagerOf<TA, VW, BM, XF>::T sa;
+    typename StagerOf<TB, VW, BN, false>::T sb;
     sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K, XF ? a.xf : nullptr);
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
     // Rotated software pipeline.  Per k-tile: NG groups of 8 k (4 MFMAs per 32x32 tile each); the
     // fragments of group g+1 are read from LDS while group g multiplies.  The staging of the following
-    // tiles rides BETWEEN the MFMAs (the matrix pipe is busy 64 cycles per MFMA, the wave issues the
-    // staging instructions meanwhile): group 0 writes the staged registers of tile kt+1 to the other LDS
+    // tiles rides BETWEEN the MFMAs: group 0 writes the staged registers of tile kt+1 to the other LDS
     // buffer, one quarter per MFMA sub-step, group 1 issues the global loads of tile kt+2 the same way
-    // (global loads run ~a k-tile ahead of their LDS stores).  No branches: the last iterations re-read
-    // the last k-tile (cache hits) and write it to a buffer nobody reads.  The barrier is passed BEFORE
+    // (global loads run ~a k-tile ahead of their LDS stores).  No branches on the tile count: the last iterations
+    // re-read the last k-tile (cache hits) and write it to a buffer nobody reads.  The barrier is passed BEFORE
     // the last group of tile kt multiplies, and the first fragments of tile kt+1 are fetched right behind
     // it: the barrier skew and the LDS latency at the tile boundary hide behind that group's MFMAs.
+    // The loop is unrolled by two k-tiles so that "which buffer" is a compile-time constant.
     constexpr int NG = BK / 8;
     static_assert(NG >= 4 && (NG % 2) == 0, "the rotation needs an even number (>= 4) of k-groups per tile");
-    constexpr int G_STORE = 0, G_LOAD = 1;  // the loads overwrite the registers (and okmask) the stores read
     sa.load(kt0 * BK);
     sb.load(kt0 * BK);
 #pragma unroll
@@ -320,68 +563,20 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
     for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[0][i], As, arow + 32 * i, 0, h);
 #pragma unroll
     for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[0][j], Bs, brow + 32 * j, 0, h);
-    for (int kt = kt0; kt < kt1; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        const bool more = kt + 1 < kt1;
-        const float* Ab = As + cur * AF;
-        const float* Bb = Bs + cur * BF;
-        float* An = As + (cur ^ 1) * AF;
-        float* Bn = Bs + (cur ^ 1) * BF;
-        const int k2 = min(kt + 2, kt1 - 1) * BK;
-#pragma unroll
-        for (int g = 0; g < NG - 1; ++g) {
-            const int c = g & 1, n = c ^ 1;
-#pragma unroll
-            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[n][i], Ab, arow + 32 * i, g + 1, h);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[n][j], Bb, brow + 32 * j, g + 1, h);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int jj = 0; jj < 4; ++jj) {
-#pragma unroll
-                for (int i = 0; i < WM; ++i)
-#pragma unroll
-                    for (int j = 0; j < WN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][jj], fb[c][j][jj], acc[i][j], 0, 0, 0);
-                if (g == G_STORE) {
-                    sa.xform_part(jj);
-                    sa.store_part(An, jj);
-                    sb.store_part(Bn, jj);
-                    if constexpr (XF) {
-                        // one granule's transform (4 x {v_fma, v_exp}) rides between this sub-step's MFMAs instead of
-                        // queueing behind the last one: an MFMA keeps the matrix pipe busy for 64 cycles
-#pragma unroll
-                        for (int q = 0; q < WM * WN; ++q) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x002, (8 + WM * WN - 1) / (WM * WN), 0);  // VALU
-                        }
-                    }
-                }
-                if (g == G_LOAD) {
-                    if (jj == 0) { sa.begin_load(k2); sb.begin_load(k2); }
-                    sa.load_part(jj);
-                    sb.load_part(jj);
-                }
-                __builtin_amdgcn_sched_barrier(0);  // keep the sub-steps apart: MFMAs, then their share of staging
-            }
-        }
-        __syncthreads();
-        constexpr int cl = (NG - 1) & 1, nl = cl ^ 1;  // NG is even: the next tile's group 0 lands in slot 0
-        static_assert(nl == 0, "fragment slot rotation assumes an even number of groups per k-tile");
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < WM; ++i) read_frag<TA, BM>(fa[nl][i], An, arow + 32 * i, 0, h);
-#pragma unroll
-            for (int j = 0; j < WN; ++j) read_frag<TB, BN>(fb[nl][j], Bn, brow + 32 * j, 0, h);
-        }
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-            for (int i = 0; i < WM; ++i)
-#pragma unroll
-                for (int j = 0; j < WN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cl][i][jj], fb[cl][j][jj], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
+    // Tiles [kt0, fast_end) neither store nor load the product's partial last k-tile (a tile stores tile kt + 1 and
+    // loads tile kt + 2): they run the code without masks, in pairs; what is left (at most one such tile, and the last
+    // three when there is a partial tile) runs the masking code.
+    const bool partial = kt1 * BK > K;
+    const int fast_end = partial ? max(kt0, kt1 - 3) : kt1;
+    int kt = kt0;
+    for (; kt + 1 < fast_end; kt += 2) {
+        k_tile<TA, TB, WM, WN, XF, 0, false>(sa, sb, As, Bs, arow, brow, h, true, min(kt + 2, kt1 - 1) * BK, fa, fb, acc);
+        k_tile<TA, TB, WM, WN, XF, 1, false>(sa, sb, As, Bs, arow, brow, h, kt + 2 < kt1, min(kt + 3, kt1 - 1) * BK, fa, fb, acc);
+    }
+    for (; kt < kt1; kt += 2) {
+        k_tile<TA, TB, WM, WN, XF, 0, true>(sa, sb, As, Bs, arow, brow, h, kt + 1 < kt1, min(kt + 2, kt1 - 1) * BK, fa, fb, acc);
+        if (kt + 1 >= kt1) break;
+        k_tile<TA, TB, WM, WN, XF, 1, true>(sa, sb, As, Bs, arow, brow, h, kt + 2 < kt1, min(kt + 3, kt1 - 1) * BK, fa, fb, acc);
     }
     // every wave's LDS reads completed before the last barrier: the buffers are free for the epilogue
 }
@@ -560,7 +755,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
 // instead of one per accumulator row (32 per lane): the kernel fits 2 waves per SIMD (two
 // workgroups per CU), which is what hides the epilogue and the barrier skew behind the other
 // workgroup's MFMAs.  One 32-lane shuffle reduction per row at the very end.
-template <bool ARG, bool VEC, bool STORE>
+template <bool ARG, int VW, bool STORE>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
                                                                   int N, int K, int n_split, int tiles_per_split,
                                                                   int tiles_n, float* __restrict__ part_max,
@@ -588,7 +783,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
     for (int tn = t_begin; tn < t_end; ++tn) {
         const int n0 = tn * BN;
         f32x16 acc[2][2];
-        tile_mainloop<false, false, VEC ? 4 : 1, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
+        tile_mainloop<false, false, VW, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
         // logits (+bias; columns past N masked) -> LDS image [128][132]
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
@@ -690,7 +885,7 @@ __global__ void lse_combine_kernel(const float* __restrict__ pm, const float* __
 }
 
 // ---- DLOGITS -------------------------------------------------------------------------------------
-template <bool VEC>
+template <int VW>
 __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, const float* __restrict__ bias,
                                                                    const float* __restrict__ lse,
                                                                    const float* __restrict__ coef, int M, int N, int K,
@@ -702,7 +897,7 @@ __global__ __launch_bounds__(NTHREADS) void linear_dlogits_kernel(OpA a, OpB b, 
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
     f32x16 acc[2][2];
-    tile_mainloop<false, false, VEC ? 4 : 1, 2, 2>(a, b, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
+    tile_mainloop<false, false, VW, 2, 2>(a, b, M, N, K, m0, n0, 0, (K + BK - 1) / BK, lds, acc);
     const int c0 = n0 + acc_col<2>(0), c1 = n0 + acc_col<2>(1);
     const bool ok0 = c0 < N, ok1 = c1 < N;
     const float b0 = (bias && ok0) ? bias[c0] : 0.f, b1 = (bias && ok1) ? bias[c1] : 0.f;
@@ -882,6 +1077,12 @@ void allow_lds(F* func, int bytes) {
 
 bool vec_ok(const float* p, int64_t ld) { return p == nullptr || (aligned16(p) && (ld % 4) == 0); }
 
+// The 16-byte stagers (FastStager) keep one 32-bit byte offset per granule relative to a per-tile scalar base: the
+// span those offsets cover -- all rows of a k-contiguous operand, 32 k rows of a transposed one -- must stay below 4 GiB
+bool fast_span_ok(int64_t ld, bool trans, int rows) {
+    return (trans ? 32 * ld + rows : (int64_t)rows * ld + 32) < ((int64_t)1 << 30);
+}
+
 // widest granule (4, 2 or 1 floats) that every load of an operand can use: base alignment, leading dimension
 // and the extent the granules run along (K for a k-contiguous operand, the row count for a transposed one)
 int operand_vw(const float* p, int64_t ld, bool trans, int rows, int K) {
@@ -1023,7 +1224,9 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
     OpB b;
     b.p = B; b.ld = ldb;
     // widest granule both operands allow: every granule is aligned and entirely in or out of range
-    const int vw = min(operand_vw(A, lda, trans_a != 0, M, K), operand_vw(B, ldb, trans_b != 0, N, K));
+    int vw = min(operand_vw(A, lda, trans_a != 0, M, K), operand_vw(B, ldb, trans_b != 0, N, K));
+    // the 16-byte stagers take one panel, no row gather, 32-bit offsets: anything else runs on 8-byte granules
+    if (vw == 4 && (a_rows || !fast_span_ok(lda, trans_a != 0, M) || !fast_span_ok(ldb, trans_b != 0, N))) vw = 2;
     hipStream_t s = (hipStream_t)stream;
 #define GO(TA, TB)                                                                                                  \
     do {                                                                                                            \
@@ -1099,6 +1302,7 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
         q.M = x.M; q.N = x.N; q.K = x.K;
         q.cvec = aligned16(x.C) && (x.ldc % 4) == 0 && (x.N % 4) == 0;
         vw = min(vw, min(operand_vw(x.A, x.lda, trans_a != 0, x.M, x.K), operand_vw(x.B, x.ldb, trans_b != 0, x.N, x.K)));
+        if (vw == 4 && (!fast_span_ok(x.lda, trans_a != 0, x.M) || !fast_span_ok(x.ldb, trans_b != 0, x.N))) vw = 2;
         const int64_t tm = (x.M + 127) / 128, nk = (x.K + BK - 1) / BK;
         padded128 += tm * ((x.N + 127) / 128) * nk * 1000;
         padded64 += tm * ((x.N + 63) / 64) * nk * 535;
@@ -1133,23 +1337,31 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
     OpB b;
     b.p = W; b.ld = ldw;
     vec = vec && vec_ok(W, ldw);
+    // 16-byte granules (the fast stagers) want ONE activation panel; two panels ([h | e] as separate tensors) run
+    // on 8-byte granules -- callers that can should concatenate (dss_vae_amd/ops.py does)
+    const int vw = !vec ? 1 : ((Ke == 0 && fast_span_ok(ldh, false, M) && fast_span_ok(ldw, false, N)) ? 4 : 2);
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
     if (n_split > tiles_n) return DSSVAE_EINVAL;
     const int tps = tiles_n / n_split;  // rounded down: the kernel deals the remainder one tile each
     hipStream_t s = (hipStream_t)stream;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
     const int lvec = logits && aligned16(logits) && (ldl % 4) == 0 && (N % 4) == 0;
-#define GO(ARG, VEC, ST)                                                                                          \
+#define GO1(ARG, VW, ST)                                                                                         \
     do {                                                                                                          \
-        allow_lds(linear_lse_kernel<ARG, VEC, ST>, lds_bytes);                                                    \
-        hipLaunchKernelGGL((linear_lse_kernel<ARG, VEC, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes, \
+        allow_lds(linear_lse_kernel<ARG, VW, ST>, lds_bytes);                                                     \
+        hipLaunchKernelGGL((linear_lse_kernel<ARG, VW, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes,  \
                            s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg,     \
                            logits, ldl, lvec);                                                                    \
     } while (0)
-    if (logits) { if (vec) GO(false, true, true); else GO(false, false, true); }
-    else if (want_argmax) { if (vec) GO(true, true, false); else GO(true, false, false); }
-    else { if (vec) GO(false, true, false); else GO(false, false, false); }
+#define GO(ARG, ST)                                                                                               \
+    do {                                                                                                          \
+        if (vw == 4) GO1(ARG, 4, ST); else if (vw == 2) GO1(ARG, 2, ST); else GO1(ARG, 1, ST);                    \
+    } while (0)
+    if (logits) GO(false, true);
+    else if (want_argmax) GO(true, false);
+    else GO(false, false);
 #undef GO
+#undef GO1
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -1188,15 +1400,15 @@ extern "C" int dssvae_linear_ce_dlogits(const float* Xh, int64_t ldh, int Kh, co
     const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128, ntiles = tiles_m * tiles_n;
     constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
     const int dvec = aligned16(dL) && (ldd % 4) == 0 && (N % 4) == 0;
-    if (vec) {
-        allow_lds(linear_dlogits_kernel<true>, lds_bytes);
-        hipLaunchKernelGGL(linear_dlogits_kernel<true>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
-                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles, dvec);
-    } else {
-        allow_lds(linear_dlogits_kernel<false>, lds_bytes);
-        hipLaunchKernelGGL(linear_dlogits_kernel<false>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,
-                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles, dvec);
-    }
+    const int vw = !vec ? 1 : ((Ke == 0 && fast_span_ok(ldh, false, M) && fast_span_ok(ldw, false, N)) ? 4 : 2);
+#define GO(VW)                                                                                                       \
+    do {                                                                                                             \
+        allow_lds(linear_dlogits_kernel<VW>, lds_bytes);                                                             \
+        hipLaunchKernelGGL(linear_dlogits_kernel<VW>, dim3(ntiles), dim3(NTHREADS), lds_bytes, (hipStream_t)stream,  \
+                           a, b, bias, lse, coef, M, N, Kh + Ke, dL, ldd, colsum, tiles_n, ntiles, dvec);            \
+    } while (0)
+    if (vw == 4) GO(4); else if (vw == 2) GO(2); else GO(1);
+#undef GO
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -1268,7 +1480,8 @@ extern "C" int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int row
     if (beta != 0.f && beta != 1.f) return DSSVAE_EINVAL;
     // 16-byte granules everywhere: the caller falls back to dssvae_softmax_grad_inplace + dssvae_gemm_f32 otherwise
     if (!aligned16(logits) || (ldl % 4) != 0 || (cols % 4) != 0 || !aligned16(B) ||
-        (ldb % 4) != 0 || (N % 4) != 0)
+        (ldb % 4) != 0 || (N % 4) != 0 || !fast_span_ok(ldl, trans_a != 0, trans_a ? cols : rows) ||
+        !fast_span_ok(ldb, true, N))
         return DSSVAE_ETOOBIG;
     OpA a;
     a.p1 = logits; a.ld1 = ldl; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr;

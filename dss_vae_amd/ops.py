@@ -635,7 +635,16 @@ def _pick_split(M, N):
     return max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
 
 
+def _one_panel(xh, xe):
+    """[xh | xe] as ONE row-major matrix: the projection kernels' 16-byte stagers take a single activation panel (two
+    panels run on 8-byte granules, ~8 % slower); the copy is M x K floats against a product of 2 M V K flops"""
+    return torch.cat((xh, xe), dim=1)
+
+
 def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None):
+    if xe is not None and Ke > 0 and (Kh + Ke) % 4 == 0:
+        xh, xe = _one_panel(xh[:M], xe[:M]), None
+        ldh, Kh, lde, Ke = xh.stride(0), Kh + Ke, 0, 0
     S = _pick_split(M, N)
     dev = xh.device
     pm = torch.empty(M, S, device=dev, dtype=torch.float32)
@@ -770,7 +779,7 @@ class _LinearCEFn(Function):
             ones = None if fuse else torch.ones(M, T, device=dev, dtype=torch.float32)
             rowinfo = torch.empty(M, device=dev, dtype=torch.float32) if fuse else None
             xcat = None
-            if need_w:
+            if need_w or xe is not None:   # (one activation panel for the projection kernels as well: _one_panel)
                 parts = [xh] if xe is None else [xh, xe]
                 if Kw > K:
                     parts.append(_ones_col(M, dev))
@@ -788,12 +797,15 @@ class _LinearCEFn(Function):
             wg_done = None  # event: the previous chunk's wgrad (accumulation into dW) has finished
             for ci, m0 in enumerate(range(0, M, mc)):
                 rows = min(mc, M - m0)
-                xh_c = xh[m0:m0 + rows]
-                xe_c = None if xe is None else xe[m0:m0 + rows]
                 st = streams[ci % n_str]
                 with torch.cuda.stream(st):
                     dl = slabs[ci % n_str][:rows]
-                    _lse(xh_c, ldh, Kh, xe_c, lde, Ke, W, ldw, b, rows, N, logits=dl, lse_out=lse[m0:m0 + rows])
+                    if xe is not None:   # [h | e (| 1 0 0 0)] is one matrix already: its first K columns
+                        _lse(xcat[m0:m0 + rows], xcat.stride(0), K, None, 0, 0, W, ldw, b, rows, N, logits=dl,
+                             lse_out=lse[m0:m0 + rows])
+                    else:
+                        _lse(xh[m0:m0 + rows], ldh, Kh, None, 0, 0, W, ldw, b, rows, N, logits=dl,
+                             lse_out=lse[m0:m0 + rows])
                     if fuse:
                         L.check(lib.dssvae_ce_rowinfo(L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, L.ptr(rowinfo[m0:]),
                                                       L.stream()), "dssvae_ce_rowinfo")
