@@ -38,8 +38,12 @@
 // (loaded again, never multiplied) rather than left to the range check: every load of the stream then returns through
 // the same path, so the in-order return that s_waitcnt vmcnt(n > 0) counts on does not hang on how the hardware
 // retires an out-of-range load (a precaution -- no failure was traced to it).
-// All workgroups of a launch must be co-resident: the host caps the grid at the CU count (1
-// workgroup per CU); every spin is bounded and reports through an error word instead of hanging.
+// All workgroups of a launch must be co-resident: the host admits a grid only up to the runtime's occupancy for
+// the kernel at the launch's LDS slice and block size x the CU count (dssvae_gru_resident_workgroups: 1 to 2
+// workgroups per CU at these slices), else DSSVAE_ETOOBIG; every spin is bounded and reports through an error
+// word instead of hanging.  The bound is for a chip the launch has to itself or shares with kernels whose
+// workgroups retire (GEMMs, collectives): two persistent launches must never overlap each other (ops._PersistentTurn
+// serialises them across streams), and host threads launching them concurrently must do the same.
 //
 // Roofline: per step 2*B*H*3H flop on fp32 MFMA; in practice latency-bound by the step hand-off.
 #include "common.h"
@@ -1162,4 +1166,39 @@ extern "C" int dssvae_gru_check(void* workspace, void* stream) {
     e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) return (int)e;
     return err ? DSSVAE_ETIMEOUT : DSSVAE_OK;
+}
+
+// ---- residency rehearsal --------------------------------------------------------------------------------------
+// A neighbour that STAYS on the chip: `workgroups` workgroups of 256 threads, each holding `lds_bytes` of LDS, wait
+// until the host writes a non-zero word to `release` (coherent host memory, read with a system-scope load by one
+// lane per workgroup) or `max_ms` have passed on the 100 MHz wall clock -- the exit every wave reaches.  What a
+// communication kernel looks like to a persistent recurrence launched beside it (tests/test_overlap_gpu.py).
+namespace {
+__global__ __launch_bounds__(256) void hold_cus_kernel(const unsigned* release, unsigned long long max_ticks,
+                                                       unsigned long long* held_ticks) {
+    extern __shared__ unsigned hold_lds[];  // the launch's dynamic LDS: held, not used
+    const unsigned long long t0 = wall_clock64();
+    if (threadIdx.x == 0) {
+        unsigned long long now = t0;
+        while (now - t0 < max_ticks) {
+            if (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) break;
+            __builtin_amdgcn_s_sleep(64);
+            now = wall_clock64();
+        }
+        if (held_ticks) held_ticks[blockIdx.x] = now - t0;
+        hold_lds[0] = (unsigned)(now - t0);
+    }
+    __syncthreads();  // the other three waves wait here, resident
+}
+}  // namespace
+
+extern "C" int dssvae_hold_cus(const uint32_t* release, int workgroups, int lds_bytes, int max_ms,
+                               unsigned long long* held_ticks, void* stream) {
+    if (!release || workgroups < 1 || workgroups > 256 || lds_bytes < 4 || lds_bytes > 64 * 1024 || max_ms < 1 ||
+        max_ms > 5000)
+        return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(workgroups), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, release,
+                       (unsigned long long)max_ms * 100000ull, held_ticks);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
 }

@@ -99,6 +99,7 @@ _SIGNATURES = {
     "dssvae_gru_bwd": ([C.POINTER(GruBwdInst), _I, _P, _L, _P], _I),
     "dssvae_gru_check": ([_P, _P], _I),
     "dssvae_gru_error_word": ([_P], _I),
+    "dssvae_hold_cus": ([_P, _I, _I, _I, _P, _P], _I),
     "dssvae_gru_cell": ([_P, _P, _P, _I, _I, _P, _P], _I),
     "dssvae_gru_step_fwd": ([_P, _L, _P, _P, _P, _P, _I, _I, _I, _P, _P, _L, _P, _L, _P], _I),
     "dssvae_gru_step_bwd": ([_P, _L, _P, _L, _P, _P, _I, _I, _I, _P, _P, _L, _P, _P], _I),

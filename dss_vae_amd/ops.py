@@ -1265,6 +1265,28 @@ class _PersistentTurn(object):
         return False
 
 
+class ResidentNeighbour(object):
+    """residency rehearsal (dssvae_hold_cus): `workgroups` x 256 threads holding `lds_bytes` each stay on the chip,
+    on a stream of their own, until release() -- or max_ms, whichever comes first.  `held_ms()` afterwards = how long
+    each workgroup stayed."""
+
+    def __init__(self, workgroups=48, lds_bytes=32 * 1024, max_ms=2000, device=None):
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.flag = torch.zeros(1, dtype=torch.int32).pin_memory()
+        self.ticks = torch.zeros(workgroups, device=dev, dtype=torch.int64)
+        self.stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.device(dev):
+            L.check(L.load().dssvae_hold_cus(self.flag.data_ptr(), workgroups, lds_bytes, max_ms,
+                                             self.ticks.data_ptr(), self.stream.cuda_stream), "dssvae_hold_cus")
+
+    def release(self):
+        self.flag[0] = 1
+
+    def held_ms(self):
+        self.stream.synchronize()
+        return (self.ticks.cpu().double() / 1e5).tolist()
+
+
 def check_persistent_errors():
     """raise if any persistent GRU launch since the last call timed out waiting for a peer workgroup
     (its results are then garbage).  One device sync: call it where the loop synchronises anyway."""

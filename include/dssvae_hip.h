@@ -78,14 +78,16 @@ int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* problems_host, int n, int
                             void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Fused vocabulary projection + online log-sum-exp (logits are never written).
+ * Fused vocabulary projection + online log-sum-exp (generation and the bag-of-words heads never write logits; the
+ * training path asks for them ONCE as a side output, see `logits`).
  *   logit[m,n] = Xh[m,:Kh] . W[n,:Kh] + Xe[m,:Ke] . W[n,Kh:Kh+Ke] + bias[n]
  * dssvae_linear_lse_fwd writes, per row m and column split s (n_split of them), the running
  * max and sum(exp(logit - max)) of that split into part_max/part_sum [M, n_split]; with
  * want_argmax it also writes the split's best column into part_arg [M, n_split].
  * logits (may be NULL): side output, the logits of these M rows into a caller slab [M, ldl]
- * (the training path passes a row chunk of up to 512 MiB and turns it into dlogits in place with
- * dssvae_softmax_grad_inplace, so backward never recomputes the projection).
+ * (the training path passes a row chunk of a slab of up to 1024 MiB per head and backward reads it back through
+ * dssvae_gemm_f32_dlogits, which applies the softmax gradient while staging, so the projection is never recomputed
+ * and the slab never rewritten; dssvae_softmax_grad_inplace is the unfused form of that).
  * Replaces: RNNDecoder.forward_step's `self.out(cat(output, embedded))` + F.log_softmax
  * (decoder/rnn_decoder.py:70-73,94) and the scorer Linear+LogSoftmax of the bag-of-words heads
  * (vae/enhance_syntax_vae.py:607-615).  Xe may be NULL (Ke = 0).
@@ -300,6 +302,12 @@ int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst_host, int n_inst, void* works
 int dssvae_gru_error_word(void* word);
 /* Reads the error word a persistent launch leaves in its workspace (synchronises the stream). */
 int dssvae_gru_check(void* workspace, void* stream);
+/* Residency rehearsal (diagnostic; no counterpart in the reference): `workgroups` (<= 256) workgroups of 256 threads,
+ * each holding lds_bytes (<= 64 KiB) of LDS, stay on the chip until the host writes a non-zero word to `release`
+ * (coherent pinned host memory) or max_ms (<= 5000) have passed -- what a communication kernel on another stream looks
+ * like to a persistent recurrence.  held_ticks (may be NULL) [workgroups]: 100 MHz ticks each workgroup waited. */
+int dssvae_hold_cus(const uint32_t* release, int workgroups, int lds_bytes, int max_ms, unsigned long long* held_ticks,
+                    void* stream);
 
 /* One GRU cell step from precomputed gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (greedy loop,
  * decoder/rnn_decoder.py:160-168): h_new = (1-z)*n + z*h. */

@@ -11,14 +11,51 @@ from parity_util import make_args, make_examples, product_examples, product_voca
 pytestmark = pytest.mark.gpu
 
 
-def _step(pm, exs, noise):
+def _step(pm, exs, noise, enqueued=None):
     for p in pm.parameters():
         p.grad = None
     pm.noise = dict(noise)
     ret = pm.get_loss(product_examples(exs), 6000)
     torch.mean(ret["Loss"]).backward()
+    if enqueued is not None:
+        enqueued()
     torch.cuda.synchronize()
     return float(ret["Loss"]), {n: p.grad.detach().clone() for n, p in pm.named_parameters() if p.grad is not None}
+
+
+def _model(n_src, n_tgt, B):
+    from dss_vae_amd.models import MODEL_CLS
+    from dss_vae_amd.train import build_model_params_
+    args = make_args(dec_ed=0.0, dec_rd=0.0, tgt_wd=False)
+    pm = MODEL_CLS["SyntaxVAE2"](args=args, vocab=product_vocab(n_src, n_tgt))
+    build_model_params_(pm, seed=3)
+    pm.cuda().train()
+    exs = make_examples(B, n_src, n_tgt, src_len=30, tree_len=90, fixed=True, seed=11)
+    gen = torch.Generator().manual_seed(5)
+    noise = {"eps_syn": torch.randn(B, 100, generator=gen), "eps_sem": torch.randn(B, 100, generator=gen)}
+    return pm, exs, noise
+
+
+@pytest.mark.parametrize("workgroups,lds_kb", [(48, 32), (64, 64)])
+def test_training_step_beside_a_resident_neighbour(workgroups, lds_kb):
+    """the neighbour does not retire: `workgroups` workgroups stay on the chip (as a collective's kernel does while
+    it waits for its peers) from before the forward until the whole backward is enqueued; every persistent launch
+    of the step is admitted beside them, finishes, and leaves a clean error word"""
+    from dss_vae_amd import ops
+    pm, exs, noise = _model(4000, 300, 256)
+    loss_q, g_q = _step(pm, exs, noise)
+    ops.check_persistent_errors()
+    torch.cuda.synchronize()
+    nb = ops.ResidentNeighbour(workgroups=workgroups, lds_bytes=lds_kb * 1024, max_ms=3000)
+    loss_b, g_b = _step(pm, exs, noise, enqueued=nb.release)
+    held = nb.held_ms()
+    ops.check_persistent_errors()  # raises if a recurrence gave up waiting for a peer
+    assert len(held) == workgroups and min(held) > 1.0, held  # resident while the step ran, not queued behind it
+    assert max(held) < 2500.0, held  # released by the host's flag, not by the time limit
+    assert abs(loss_b - loss_q) <= 1e-5 * abs(loss_q)
+    assert set(g_b) == set(g_q)
+    for n in g_q:
+        assert rel_err(g_b[n], g_q[n]) < 1e-4, (n, rel_err(g_b[n], g_q[n]))
 
 
 def test_training_step_beside_a_busy_side_stream():
