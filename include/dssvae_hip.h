@@ -284,6 +284,12 @@ int64_t dssvae_gru_workspace_bytes(int n_inst, const int32_t* B_host, const int3
  * peers): the runtime's occupancy for the kernel at this LDS slice (largest H of the launch) and block size
  * (largest cell height: 16 rows per wave) x the CU count.  A launch whose grid exceeds it returns DSSVAE_ETOOBIG. */
 int dssvae_gru_resident_workgroups(int H_max, int rows_max, int backward, int* n_host);
+/* The bound has no margin: it assumes the launch has the chip to itself or shares it with workgroups that retire
+ * (GEMMs, collectives; rehearsed beside <= 64 resident foreign workgroups of 64 KiB LDS: tests/test_overlap_gpu.py).
+ * Two persistent launches must never overlap on one GPU, whatever their streams: the Python host serialises them with
+ * events (ops._PersistentTurn); a C caller with several host threads has to do the same.  The library's launch
+ * bookkeeping (dssvae_gemm_last_launches, dssvae_decode_profile, the error word registration) is per process, not
+ * per thread. */
 /* The layout the library would run a launch of these instances in (no launch): *waves_host = waves per workgroup
  * (16: the K-split layouts; 4 / 8: one wave per row group), 0 = the grid is not resident with these cell heights.
  * rows_host[i] as dssvae_gru_*_inst.rows (0 = the library's choice).  For callers that pick cell heights per
@@ -425,7 +431,9 @@ int dssvae_decode_profile_read(double* total_ms_host, int* launches_host);
  * library (DSSVAE_DECODE_NOALLOC_BYTES per GPU the library runs on, held until the process ends); a shape whose
  * dssvae_greedy_decode_workspace_bytes(...) exceeds it returns DSSVAE_ETOOBIG with nothing launched (16 MiB
  * covers a decode batch of 128 at E=300, H=600, 2 layers, V=30000).  Same results as dssvae_greedy_decode.
- * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race. */
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (different streams) race.
+ * Under HIP graph capture: make ONE eager call on the device first (any shape) -- the array's address is taken with
+ * hipGetSymbolAddress and the kernels' code objects are loaded on first use, and neither is legal while capturing. */
 #define DSSVAE_DECODE_NOALLOC_BYTES (16u << 20)
 int dssvae_greedy_decode_noalloc(const dssvae_decode_params* params, const float* h0, int B, int max_len,
                                  int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* stream);
