@@ -637,25 +637,22 @@ __device__ __forceinline__ void tile_to_global(const f32x16 (&acc)[WM][WN], floa
 }
 
 // ---- STORE ---------------------------------------------------------------------------------------
+// k-tiles [kt0, kt1) of the output tile at (m0, n0): `atomic` adds the partial product to C (zeroed, or holding the
+// addend, by the host) and only the piece with `with_bias` adds the bias; otherwise alpha * product + bias leaves
+// through LDS as 16-byte stores (beta applied)
 template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
-__device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
-                                                const float* __restrict__ bias, int M, int N, int K, float alpha,
-                                                float beta, int tiles_n, int ksplit, int kt_per_split, int cvec,
-                                                int wid, float* lds) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
-    const int tile = wid / ksplit, ks = wid - tile * ksplit;
-    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
-    const int nk = (K + BK - 1) / BK;
-    const int kt0 = ks * kt_per_split, kt1 = min(nk, kt0 + kt_per_split);
-    if (kt0 >= kt1) return;
+__device__ __forceinline__ void store_tile_seg(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
+                                               const float* __restrict__ bias, int M, int N, int K, float alpha,
+                                               float beta, int m0, int n0, int kt0, int kt1, bool atomic,
+                                               bool with_bias, int cvec, float* lds) {
     f32x16 acc[WM][WN];
     tile_mainloop<TA, TB, VW, WM, WN, XF>(a, b, M, N, K, m0, n0, kt0, kt1, lds, acc);
-    if (ksplit > 1) {
+    if (atomic) {
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
             const int n = n0 + acc_col<WN>(nt);
             if (n >= N) continue;
-            const float bv = (bias && ks == 0) ? bias[n] : 0.f;
+            const float bv = (bias && with_bias) ? bias[n] : 0.f;
 #pragma unroll
             for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -677,6 +674,21 @@ __device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, floa
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = alpha * acc[mt][nt][r] + bv;
     }
     tile_to_global<WM, WN>(acc, lds, C, ldc, m0, n0, M, N, beta, cvec != 0);
+}
+
+template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
+__device__ __forceinline__ void store_tile_body(const OpA& a, const OpB& b, float* __restrict__ C, int64_t ldc,
+                                                const float* __restrict__ bias, int M, int N, int K, float alpha,
+                                                float beta, int tiles_n, int ksplit, int kt_per_split, int cvec,
+                                                int wid, float* lds) {
+    constexpr int BM = 64 * WM, BN = 64 * WN;
+    const int tile = wid / ksplit, ks = wid - tile * ksplit;
+    const int m0 = (tile / tiles_n) * BM, n0 = (tile % tiles_n) * BN;
+    const int nk = (K + BK - 1) / BK;
+    const int kt0 = ks * kt_per_split, kt1 = min(nk, kt0 + kt_per_split);
+    if (kt0 >= kt1) return;
+    store_tile_seg<TA, TB, VW, WM, WN, XF>(a, b, C, ldc, bias, M, N, K, alpha, beta, m0, n0, kt0, kt1, ksplit > 1,
+                                            ks == 0, cvec, lds);
 }
 
 template <bool TA, bool TB, int VW, int WM, int WN, bool XF = false>
@@ -727,25 +739,85 @@ __global__ void ce_onehot_fixup_kernel(const int64_t* __restrict__ target, int64
 // ---- grouped STORE: up to DSSVAE_GEMM_MAX_GROUP independent products of one layout in ONE launch ----
 // (the per-direction / per-head GRU projections and weight gradients are 1-3 GFLOP each: alone they
 // cannot fill the chip and pay a launch + a tail each).  C = A.B^T + bias.
+// A launch holds up to GROUP_ENTRIES tile problems; a caller's product becomes one or two of them: its full 128-wide
+// tile columns on the 128x128 tile body and, when the last tile column would be at most half full (N = 300 = 2 x 128 + 44,
+// N = 150 = 128 + 22), the remainder on the 128x64 body -- the tile shape is per problem, inside ONE launch.
+constexpr int GROUP_ENTRIES = 2 * DSSVAE_GEMM_MAX_GROUP;
 struct GroupProblem {
-    OpA a; OpB b;
+    const float* A; int64_t lda;
+    const float* B; int64_t ldb;
     float* C; int64_t ldc; const float* bias;
-    int M, N, K, tiles_n, ksplit, ktps, cvec, wg_begin;
+    int M, N, K, tiles_n, ksplit, ktps, cvec, wg_begin, narrow;
+    int tiles, unit_begin;  // stream-K launches: output tiles, and where the problem starts in the launch's unit list
 };
 struct GroupArgs {
-    GroupProblem p[DSSVAE_GEMM_MAX_GROUP];
+    GroupProblem p[GROUP_ENTRIES];
     int n;
+    int units, per;  // stream-K launches: length of the unit list, units per workgroup
 };
+// stream-K: a k-tile of a 128x128 tile is SK_WIDE units of work, one of a 128x64 tile SK_NARROW (0.535 of it, measured)
+constexpr int SK_WIDE = 15, SK_NARROW = 8;
 
-template <bool TA, bool TB, int VW, int WM, int WN>
+template <bool TA, bool TB, int VW>
 __global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // each XCD (blockIdx % 8) works on a contiguous stretch of the launch's tile list: neighbouring tiles share an
+    // operand panel, and an XCD's L2 is its own
+    // (in windows of 64 workgroups, 8 neighbouring tiles per XCD: a contiguous eighth of the WHOLE launch per XCD
+    // would give the XCDs problems of different cost -- measured: 0.49 -> 0.74 ms on a five-problem launch)
+    const int full = (int)gridDim.x & ~63, b0 = (int)blockIdx.x;
+    const int bid = b0 < full ? (b0 & ~63) + ((b0 & 7) << 3) + ((b0 >> 3) & 7) : b0;
     int i = 0;
-    while (i + 1 < g.n && (int)blockIdx.x >= g.p[i + 1].wg_begin) ++i;
+    while (i + 1 < g.n && bid >= g.p[i + 1].wg_begin) ++i;
     const GroupProblem& q = g.p[i];
+    OpA a;
+    a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr;
+    OpB b;
+    b.p = q.B; b.ld = q.ldb;
+    const int wid = bid - q.wg_begin;
     // one workgroup per tile: plain store; split K: fp32 atomics into the C the host has zero-filled
-    store_tile_body<TA, TB, VW, WM, WN>(q.a, q.b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, q.tiles_n, q.ksplit,
-                                         q.ktps, q.cvec, (int)blockIdx.x - q.wg_begin, lds);
+    if (q.narrow)
+        store_tile_body<TA, TB, VW, 2, 1>(a, b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, q.tiles_n, q.ksplit, q.ktps,
+                                           q.cvec, wid, lds);
+    else
+        store_tile_body<TA, TB, VW, 2, 2>(a, b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, q.tiles_n, q.ksplit, q.ktps,
+                                           q.cvec, wid, lds);
+}
+
+// Stream-K form of the grouped launch, for groups with few output tiles and long K (the weight gradients: 24 .. 99
+// tiles, 240 .. 728 k-tiles each).  All k-tiles of all tiles of all problems form ONE list, weighted by tile shape;
+// every workgroup takes an equal contiguous share of it -- whole tiles leave as plain stores, pieces as atomics into the
+// zero-filled output -- so the launch is exactly one full round of the chip, whatever the tile counts are (a split
+// factor per tile fills 441 of 512 slots at best on the decoder's weight-gradient pair).
+template <bool TA, bool TB, int VW>
+__global__ __launch_bounds__(NTHREADS) void gemm_group_sk_kernel(GroupArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lo = (int)blockIdx.x * g.per, hi = min(g.units, lo + g.per);
+    for (int i = 0; i < g.n; ++i) {
+        const GroupProblem& q = g.p[i];
+        const int w = q.narrow ? SK_NARROW : SK_WIDE;
+        const int nk = (q.K + BK - 1) / BK, total = q.tiles * nk;
+        int f = min((max(lo - q.unit_begin, 0) + w - 1) / w, total);
+        const int f_hi = min((max(hi - q.unit_begin, 0) + w - 1) / w, total);
+        if (f >= f_hi) continue;
+        OpA a;
+        a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr;
+        OpB b;
+        b.p = q.B; b.ld = q.ldb;
+        while (f < f_hi) {
+            const int tile = f / nk, kt0 = f - tile * nk, kt1 = min(nk, kt0 + (f_hi - f));
+            const bool whole = kt0 == 0 && kt1 == nk;
+            const int m0 = (tile / q.tiles_n) * 128, n0 = (tile % q.tiles_n) * (q.narrow ? 64 : 128);
+            __syncthreads();  // the previous piece's LDS reads (and a plain store's tile image) are done with
+            if (q.narrow)
+                store_tile_seg<TA, TB, VW, 2, 1>(a, b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, m0, n0, kt0, kt1,
+                                                  !whole, kt0 == 0, q.cvec, lds);
+            else
+                store_tile_seg<TA, TB, VW, 2, 2>(a, b, q.C, q.ldc, q.bias, q.M, q.N, q.K, 1.f, 0.f, m0, n0, kt0, kt1,
+                                                  !whole, kt0 == 0, q.cvec, lds);
+            f += kt1 - kt0;
+        }
+    }
 }
 
 // ---- LSE (optionally with argmax) ----------------------------------------------------------------
@@ -1241,42 +1313,82 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
 
 namespace {
 
-template <bool TA, bool TB, int VW, int WM, int WN>
-int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t s) {
-    constexpr int BM = 64 * WM, BN = 64 * WN;
+// k-tiles per workgroup of a narrow (128x64) entry for `ktps` of a wide one: equal time (a 128x64 k-tile takes 0.535
+// of a 128x128 one), so that the workgroups of a launch finish together
+inline int narrow_ktps(int ktps) { return (ktps * 15 + 7) / 8; }
+
+template <bool TA, bool TB, int VW>
+int launch_group(GroupArgs& g, const float* const* c_full, const int64_t* c_ld, const int* c_m, const int* c_n,
+                 const int* owner, int n_orig, hipStream_t s) {
     // one k-tile count per workgroup for the whole group (they finish together): the smallest that keeps
     // the launch within one round of 2 workgroups per CU (and >= 4 k-tiles per workgroup)
     const int slots = 2 * n_cus_cached();
     int nk_max = 1;
-    for (int i = 0; i < n; ++i) nk_max = max(nk_max, (pr[i].K + BK - 1) / BK);
-    int ktps = min(4, nk_max);
-    for (;; ++ktps) {
-        int64_t wgs = 0;
-        for (int i = 0; i < n; ++i) {
-            const int nk = (pr[i].K + BK - 1) / BK;
-            wgs += (int64_t)((pr[i].M + BM - 1) / BM) * ((pr[i].N + BN - 1) / BN) * ((nk + ktps - 1) / ktps);
+    for (int i = 0; i < g.n; ++i) nk_max = max(nk_max, (g.p[i].K + BK - 1) / BK);
+    auto wgs_of = [&](const GroupProblem& q, int ktps) {
+        const int nk = (q.K + BK - 1) / BK, bn = q.narrow ? 64 : 128;
+        const int kt = min(nk, q.narrow ? narrow_ktps(ktps) : ktps);
+        return (int64_t)((q.M + 127) / 128) * ((q.N + bn - 1) / bn) * ((nk + kt - 1) / kt);
+    };
+    constexpr int lds_bytes = lds_floats<TA, TB, 2, 2>() * 4;
+    static_assert(lds_floats<TA, TB, 2, 1>() <= lds_floats<TA, TB, 2, 2>(), "the wide body sizes the launch's LDS");
+    int ktps = tune_env("DSSVAE_GROUP_KTPS", 0);  // development knob
+    // stream-K when the group has too few tiles to fill the chip by itself and enough k-tiles to share out
+    int64_t tiles_all = 0, units = 0;
+    for (int i = 0; i < g.n; ++i) {
+        GroupProblem& q = g.p[i];
+        const int nk = (q.K + BK - 1) / BK, bn = q.narrow ? 64 : 128;
+        q.tiles_n = (q.N + bn - 1) / bn;
+        q.tiles = ((q.M + 127) / 128) * q.tiles_n;
+        q.unit_begin = (int)units;
+        tiles_all += q.tiles;
+        units += (int64_t)q.tiles * nk * (q.narrow ? SK_NARROW : SK_WIDE);
+    }
+    const int sk_mode = tune_env("DSSVAE_GROUP_SK", 1);
+    if (ktps <= 0 && sk_mode && units < (1 << 30) && 2 * tiles_all <= 3 * slots && units >= (int64_t)slots * 6 * SK_WIDE) {
+        DssvaeZeroMany zm;
+        zm.n = 0; zm.blk_begin[0] = 0;
+        for (int i = 0; i < n_orig; ++i) dssvae_zero_many_add(zm, const_cast<float*>(c_full[i]), c_ld[i], c_m[i], c_n[i]);
+        const int e = dssvae_zero_many_launch(zm, s);
+        if (e != DSSVAE_OK) return e;
+        g.units = (int)units;
+        g.per = (int)((units + slots - 1) / slots);
+        const int wgs = (int)((units + g.per - 1) / g.per);
+        auto kern = gemm_group_sk_kernel<TA, TB, VW>;
+        allow_lds(kern, lds_bytes);
+        hipLaunchKernelGGL(kern, dim3(wgs), dim3(NTHREADS), lds_bytes, s, g);
+        DSSVAE_CHECK_LAUNCH();
+        return DSSVAE_OK;
+    }
+    if (ktps <= 0) {
+        ktps = min(4, nk_max);
+        for (;; ++ktps) {
+            int64_t wgs = 0;
+            for (int i = 0; i < g.n; ++i) wgs += wgs_of(g.p[i], ktps);
+            if (wgs <= slots || ktps >= nk_max) break;
         }
-        if (wgs <= slots || ktps >= nk_max) break;
     }
     int wg = 0;
-    DssvaeZeroMany zm;
-    zm.n = 0; zm.blk_begin[0] = 0;
-    for (int i = 0; i < n; ++i) {
+    bool split[DSSVAE_GEMM_MAX_GROUP] = {};
+    for (int i = 0; i < g.n; ++i) {
         GroupProblem& q = g.p[i];
-        const int nk = (pr[i].K + BK - 1) / BK;
-        q.tiles_n = (pr[i].N + BN - 1) / BN;
-        q.ktps = min(ktps, nk);
+        const int nk = (q.K + BK - 1) / BK, bn = q.narrow ? 64 : 128;
+        q.tiles_n = (q.N + bn - 1) / bn;
+        q.ktps = min(nk, q.narrow ? narrow_ktps(ktps) : ktps);
         q.ksplit = (nk + q.ktps - 1) / q.ktps;
         q.wg_begin = wg;
-        wg += ((pr[i].M + BM - 1) / BM) * q.tiles_n * q.ksplit;
-        if (q.ksplit > 1) dssvae_zero_many_add(zm, q.C, q.ldc, q.M, q.N);  // all split outputs in one fill launch
+        wg += ((q.M + 127) / 128) * q.tiles_n * q.ksplit;
+        if (q.ksplit > 1) split[owner[i]] = true;
     }
+    DssvaeZeroMany zm;
+    zm.n = 0; zm.blk_begin[0] = 0;
+    for (int i = 0; i < n_orig; ++i)  // all split outputs in one fill launch
+        if (split[i]) dssvae_zero_many_add(zm, const_cast<float*>(c_full[i]), c_ld[i], c_m[i], c_n[i]);
     {
         const int e = dssvae_zero_many_launch(zm, s);
         if (e != DSSVAE_OK) return e;
     }
-    constexpr int lds_bytes = lds_floats<TA, TB, WM, WN>() * 4;
-    auto kern = gemm_group_kernel<TA, TB, VW, WM, WN>;
+    auto kern = gemm_group_kernel<TA, TB, VW>;
     allow_lds(kern, lds_bytes);
     hipLaunchKernelGGL(kern, dim3(wg), dim3(NTHREADS), lds_bytes, s, g);
     DSSVAE_CHECK_LAUNCH();
@@ -1288,35 +1400,49 @@ int launch_group(GroupArgs& g, const dssvae_gemm_problem* pr, int n, hipStream_t
 extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int trans_a, int trans_b, void* stream) {
     if (!pr || n <= 0 || n > DSSVAE_GEMM_MAX_GROUP) return DSSVAE_EINVAL;
     GroupArgs g;
-    g.n = n;
+    g.n = 0;
     int vw = 4;
-    int64_t padded128 = 0, padded64 = 0;
+    const float* c_full[DSSVAE_GEMM_MAX_GROUP];
+    int64_t c_ld[DSSVAE_GEMM_MAX_GROUP];
+    int c_m[DSSVAE_GEMM_MAX_GROUP], c_n[DSSVAE_GEMM_MAX_GROUP], owner[GROUP_ENTRIES];
+    // development knobs: 64 / 128 force the tile width, 1 = no mixing (DSSVAE_GROUP_TILE: grouped launches only)
+    const int force = tune_env("DSSVAE_GROUP_TILE", tune_env("DSSVAE_GEMM_TILE", 0));
     for (int i = 0; i < n; ++i) {
         const dssvae_gemm_problem& x = pr[i];
         if (!x.A || !x.B || !x.C || x.M <= 0 || x.N <= 0 || x.K <= 0 || x.ldc < x.N) return DSSVAE_EINVAL;
         if ((trans_a ? x.lda < x.M : x.lda < x.K) || (trans_b ? x.ldb < x.N : x.ldb < x.K)) return DSSVAE_EINVAL;
-        GroupProblem& q = g.p[i];
-        q.a.p1 = x.A; q.a.ld1 = x.lda; q.a.K1 = x.K; q.a.p2 = nullptr; q.a.ld2 = 0; q.a.rows = nullptr; q.a.xf = nullptr;
-        q.b.p = x.B; q.b.ld = x.ldb;
-        q.C = x.C; q.ldc = x.ldc; q.bias = x.bias;
-        q.M = x.M; q.N = x.N; q.K = x.K;
-        q.cvec = aligned16(x.C) && (x.ldc % 4) == 0 && (x.N % 4) == 0;
         vw = min(vw, min(operand_vw(x.A, x.lda, trans_a != 0, x.M, x.K), operand_vw(x.B, x.ldb, trans_b != 0, x.N, x.K)));
         if (vw == 4 && (!fast_span_ok(x.lda, trans_a != 0, x.M) || !fast_span_ok(x.ldb, trans_b != 0, x.N))) vw = 2;
-        const int64_t tm = (x.M + 127) / 128, nk = (x.K + BK - 1) / BK;
-        padded128 += tm * ((x.N + 127) / 128) * nk * 1000;
-        padded64 += tm * ((x.N + 63) / 64) * nk * 535;
+        c_full[i] = x.C; c_ld[i] = x.ldc; c_m[i] = x.M; c_n[i] = x.N;
+        // tile shape of THIS product: full 128-wide tile columns + a 64-wide remainder column, or all of it in
+        // one width (a 128x64 k-tile takes 0.535 of a 128x128 one)
+        // Measured on the step's groups (tools/group_sweep.py): below ~6 tile columns the 128x64 body wins whatever the
+        // remainder is (more and shorter workgroups, three instead of two per CU: nn 4 x 7680x300x450 0.134 -> 0.104 ms,
+        // nn 23296x300x900 0.151 -> 0.131, tn 1800x600x7936 + 900x300x23296 0.357 -> 0.333); from N = 900 up the wide /
+        // mixed split does (nt 5 x ..x900x300: 0.482 against 0.500)
+        const int rem = x.N % 128, n_main = x.N - rem;
+        const bool small_n = x.N < 768;
+        const bool mixed = force == 0 && !small_n && n_main > 0 && rem > 0 && rem <= 64;
+        const bool narrow = force == 64 || (force != 128 && !mixed &&
+                                            (small_n || ((x.N + 63) / 64) * 535 < ((x.N + 127) / 128) * 1000));
+        for (int part = 0; part < (mixed ? 2 : 1); ++part) {
+            const int c0 = part ? n_main : 0, cols = mixed ? (part ? rem : n_main) : x.N;
+            GroupProblem& q = g.p[g.n];
+            owner[g.n++] = i;
+            q.A = x.A; q.lda = x.lda;
+            q.B = x.B + (trans_b ? (int64_t)c0 : (int64_t)c0 * x.ldb); q.ldb = x.ldb;
+            q.C = x.C + c0; q.ldc = x.ldc; q.bias = x.bias ? x.bias + c0 : nullptr;
+            q.M = x.M; q.N = cols; q.K = x.K;
+            q.narrow = mixed ? part : (narrow ? 1 : 0);
+            q.cvec = aligned16(q.C) && (x.ldc % 4) == 0 && (cols % 4) == 0;
+        }
     }
-    const bool narrow = padded64 < padded128;  // less (efficiency-weighted) padded work in 128x64 tiles
     hipStream_t s = (hipStream_t)stream;
 #define GO(TA, TB)                                                                                   \
     do {                                                                                             \
-        if (vw == 4) return narrow ? launch_group<TA, TB, 4, 2, 1>(g, pr, n, s)                      \
-                                   : launch_group<TA, TB, 4, 2, 2>(g, pr, n, s);                     \
-        if (vw == 2) return narrow ? launch_group<TA, TB, 2, 2, 1>(g, pr, n, s)                      \
-                                   : launch_group<TA, TB, 2, 2, 2>(g, pr, n, s);                     \
-        return narrow ? launch_group<TA, TB, 1, 2, 1>(g, pr, n, s)                                   \
-                      : launch_group<TA, TB, 1, 2, 2>(g, pr, n, s);                                  \
+        if (vw == 4) return launch_group<TA, TB, 4>(g, c_full, c_ld, c_m, c_n, owner, n, s);         \
+        if (vw == 2) return launch_group<TA, TB, 2>(g, c_full, c_ld, c_m, c_n, owner, n, s);         \
+        return launch_group<TA, TB, 1>(g, c_full, c_ld, c_m, c_n, owner, n, s);                      \
     } while (0)
     if (trans_a) { if (trans_b) GO(true, true); else GO(true, false); }
     else { if (trans_b) GO(false, true); else GO(false, false); }
