@@ -59,7 +59,9 @@ constexpr int CHB = 6;   // ... backward (measured: 8 -> 6 takes 6 % off the bac
 constexpr unsigned SPIN_LIMIT = 1u << 24;
 constexpr int CNT_STRIDE = 32;  // one 128-B line per counter
 constexpr int PART_BYTES = 64 * 16;      // LDS per non-lead wave and partial sum (forward: 3 gates; backward: 1)
-constexpr int SYNC_WORDS = 64;           // LDS words behind them: [0,16) release per row group, [32,64) done per wave
+constexpr int SYNC_WORDS = 64;           // LDS words behind them: [0,16) release per row group, [16,32) saved values
+                                         // of the next step staged (backward), [32,64) done per wave
+constexpr int SV_BYTES = 64 * 16;        // backward: one staged saved-value vector of a row group (16 B per lane)
 constexpr int LDS_MAX = 160 * 1024;
 constexpr int LDS_BUDGET = 150 * 1024;  // W_hh slice of a workgroup
 constexpr int MAX_WG_PER_CU = 4;
@@ -87,6 +89,7 @@ struct BwdDev {
 struct BwdArgs {
     BwdDev inst[DSSVAE_GRU_MAX_INST];
     int n_inst;
+    int sv_stage;  // the launch's LDS has room for the staged saved values of every instance (see gru_bwd_kernel)
     unsigned* err;
     unsigned* sticky;
 };
@@ -148,6 +151,9 @@ __device__ __forceinline__ void await(unsigned* cnt, unsigned target, ErrWords e
 // lead wave (part 0) polls the row group's counter and releases the others through an LDS word (the relayed form
 // of the hand-off table's first row: "the other waves load ... after an LDS word it then sets"); the others leave
 // their partial sums in LDS and raise a word each; the lead adds them up, applies the gate math and publishes.
+#ifndef LDS_POLL_SLEEP
+#define LDS_POLL_SLEEP 1
+#endif
 typedef __attribute__((address_space(3))) volatile unsigned lds_word;  // LDS address space: ds_ instructions, not flat
 __device__ __forceinline__ void lds_signal(lds_word* w, unsigned v) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // what this wave wrote to LDS before is there
@@ -156,7 +162,7 @@ __device__ __forceinline__ void lds_signal(lds_word* w, unsigned v) {
 __device__ __forceinline__ void lds_await(lds_word* w, unsigned target, ErrWords err) {
     unsigned spins = 0;
     while (*w < target) {
-        __builtin_amdgcn_s_sleep(0);
+        __builtin_amdgcn_s_sleep(LDS_POLL_SLEEP);
         if ((++spins & 4095u) == 0 &&
             (spins > SPIN_LIMIT || __hip_atomic_load(err.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u)) {
             raise_timeout(err);
@@ -417,6 +423,8 @@ __global__ __launch_bounds__(64 * WV) void gru_fwd_kernel(FwdArgs args) {
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
         } else {
             PROFP(0);
+            // (measured: every part polling the row group's counter itself instead of this relay -- four times the
+            // polls on the counter's line -- makes the forward launches 29 - 34 % slower: 0.955 -> 1.231 ms)
             lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
             PROFP(1);
         }
@@ -574,6 +582,11 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     f32x4* parts = reinterpret_cast<f32x4*>(Ws + NQ * 256);
     lds_word* sync = (lds_word*)(parts + (WV - WVI) * 64);
     const int slot0 = rg * (KS - 1);
+    // behind the sync words: the NV saved-value vectors of the NEXT step per row group, staged by the row group's
+    // part 1 while the lead is busy with this step (see the step loop)
+    constexpr int NV = LSTM ? 7 : 6;
+    f32x4* svbuf = parts + (WV - WVI) * 64 + SYNC_WORDS / 4 + rg * NV * 64 + lane;
+    lds_word* sv_ready = sync + 16 + rg;
 
     for (int idx = threadIdx.x; idx < NQ * 256; idx += NTHR) {
         const int q = idx >> 8, rem = idx & 255;
@@ -621,6 +634,47 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
     const uintptr_t st_bits = reinterpret_cast<uintptr_t>(dgx_p) | reinterpret_cast<uintptr_t>(dgh_p);
     const bool fast4s = (H % 4) == 0 && (st_bits % 16) == 0;
     const bool fast2s = !fast4s && (H % 2) == 0 && (st_bits % 8) == 0;
+    // The saved values of a step (upstream gradient, gates, previous state: NV 16-byte vectors per lane), every one in
+    // ONE memory round trip: unconditional 16-byte (H % 4 == 0) or 8-byte (H % 2 == 0) loads back to back at clamped
+    // addresses, masked afterwards (vd).
+    auto sv_fetch = [&](int step_n, f32x4 (&v)[NV]) {
+        const int fs = in.t0 + T - 1 - step_n;
+        const int tt = in.reverse ? Tt - 1 - fs : fs;
+        const size_t bt = (size_t)(row_ok ? b : 0) * Tt + tt;
+        const float* grow = gates_p + bt * (LSTM ? 7 : 5) * H;
+        const float* go_row = dout_p ? dout_p + bt * ldd : grow;
+        if (fast4) {
+            const int uc = min(ub, H - 4);
+            auto ld = [&](const float* row) { return *reinterpret_cast<const f32x4*>(row + uc); };
+            v[0] = ld(go_row);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) v[1 + i] = ld(grow + i * H);
+            if constexpr (LSTM) v[6] = ld(grow + 6 * H);
+        } else {
+            const int ua = min(ub, H - 2), uh = min(ub + 2, H - 2);
+            auto ld = [&](const float* row) {
+                const f32x2 lo = *reinterpret_cast<const f32x2*>(row + ua), hi = *reinterpret_cast<const f32x2*>(row + uh);
+                return (f32x4){lo[0], lo[1], hi[0], hi[1]};
+            };
+            v[0] = ld(go_row);
+#pragma unroll
+            for (int i = 0; i < 5; ++i) v[1 + i] = ld(grow + i * H);
+            if constexpr (LSTM) v[6] = ld(grow + 6 * H);
+        }
+    };
+    // With a K split the lead never waits for them: part 1 of the row group -- idle until the lead has seen the
+    // counter -- fetches the NEXT step's vectors at the top of its step, keeps them in registers until the lead's
+    // release (the lead has read this step's by then), and leaves them in LDS.  That took the first 1.5 - 2.2 us
+    // (a memory round trip) off every step of the lead, which is the step's critical path.
+    const bool sv_stage = args.sv_stage != 0 && KS > 1 && (fast4 || fast2);
+    const bool sv_stager = sv_stage && kp == 1;
+    if (sv_stager) {
+        f32x4 v[NV];
+        sv_fetch(0, v);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) svbuf[i * 64] = v[i];
+        lds_signal(sv_ready, 1u);
+    }
     for (int step = 0; step < T; ++step) {
         PROF(0);
         // backward walks the forward order in reverse: forward steps t0 + T - 1 down to t0 of the recurrence
@@ -640,29 +694,19 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
                 // pad rows read a valid, clamped address and are masked afterwards.  The guarded per-value loads of
                 // the general path below cost a round trip EACH -- a load under a branch is waited for at the join
                 // -- which made this phase 3-7 us of every step.
-                const float* grow = gates_p + bt * (LSTM ? 7 : 5) * H;
-                f32x4 r_go, r0, r1, r2, r3, r4, r6;
+                f32x4 sv[NV];
                 bool vd[4];
-                if (fast4) {
-                    const int uc = min(ub, H - 4);
-                    auto ld = [&](const float* row) { return *reinterpret_cast<const f32x4*>(row + uc); };
-                    r_go = ld(dout_p ? dout_p + bt * ldd : grow);
-                    r0 = ld(grow); r1 = ld(grow + H); r2 = ld(grow + 2 * H); r3 = ld(grow + 3 * H); r4 = ld(grow + 4 * H);
-                    r6 = ld(grow + (LSTM ? 6 : 4) * H);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) vd[c] = row_ok && ub + 4 <= H;
+                for (int c = 0; c < 4; ++c) vd[c] = row_ok && ub + (fast4 || c >= 2 ? 4 : 2) <= H;
+                if (sv_stage) {
+                    // staged by part 1 of this row group while the previous step ran: LDS reads, no memory round trip
+                    lds_await(sv_ready, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) sv[i] = svbuf[i * 64];
                 } else {
-                    const int ua = min(ub, H - 2), uh = min(ub + 2, H - 2);
-                    auto ld = [&](const float* row) {
-                        const f32x2 lo = *reinterpret_cast<const f32x2*>(row + ua), hi = *reinterpret_cast<const f32x2*>(row + uh);
-                        return (f32x4){lo[0], lo[1], hi[0], hi[1]};
-                    };
-                    r_go = ld(dout_p ? dout_p + bt * ldd : grow);
-                    r0 = ld(grow); r1 = ld(grow + H); r2 = ld(grow + 2 * H); r3 = ld(grow + 3 * H); r4 = ld(grow + 4 * H);
-                    r6 = ld(grow + (LSTM ? 6 : 4) * H);
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) vd[c] = row_ok && ub + (c < 2 ? 2 : 4) <= H;
+                    sv_fetch(step, sv);
                 }
+                const f32x4 r_go = sv[0], r0 = sv[1], r1 = sv[2], r2 = sv[3], r3 = sv[4], r4 = sv[5], r6 = sv[NV - 1];
                 __builtin_amdgcn_sched_barrier(0);
                 const bool in_len = t < len;
 #pragma unroll
@@ -776,6 +820,13 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             await(cnt, (unsigned)(step + 1) * NS, (ErrWords){args.err, args.sticky});
             PROF(4);
             if (KS > 1) lds_signal(go, (unsigned)step + 1u);
+        } else if (sv_stager && step + 1 < T) {
+            f32x4 v[NV];
+            sv_fetch(step + 1, v);
+            lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
+#pragma unroll
+            for (int i = 0; i < NV; ++i) svbuf[i * 64] = v[i];
+            lds_signal(sv_ready, (unsigned)step + 2u);
         } else {
             lds_await(go, (unsigned)step + 1u, (ErrWords){args.err, args.sticky});
         }
@@ -927,6 +978,13 @@ inline int lds_bytes_for(bool backward, bool lstm, int H_max, int wv, int min_ro
     return slice_bytes_for(H_max, lstm) +
            (parts > 0 ? parts * (backward ? 1 : lstm ? 4 : 3) * PART_BYTES + SYNC_WORDS * 4 : 0);
 }
+// backward with a K split: what ONE instance needs when its row groups stage the next step's saved values in LDS
+// (gru_bwd_kernel: NV vectors of SV_BYTES per row group behind the instance's own slice, partial sums and sync words)
+inline int lds_bytes_staged(bool lstm, int H, int wv, int rows) {
+    const int groups = rows / 16, parts = wv - groups;
+    if (parts <= 0) return slice_bytes_for(H, lstm);
+    return slice_bytes_for(H, lstm) + parts * PART_BYTES + SYNC_WORDS * 4 + groups * (lstm ? 7 : 6) * SV_BYTES;
+}
 
 // How many workgroups of a persistent launch the chip holds AT ONCE: the runtime's occupancy answer for this
 // kernel, block size and LDS size, times the CU count.  Every workgroup of a launch must be resident (the step
@@ -959,7 +1017,7 @@ int resident_workgroups(bool backward, bool lstm, int wv, int lds_bytes) {
 // DSSVAE_GRU_WAVES=8 forces 128 rows / 8 waves, DSSVAE_GRU_KSPLIT=0 skips the K-split layouts (tests, A/B).
 // -> waves per workgroup (1 .. 16), 0 = not resident any way, -1 = bad rows value
 int pick_rows(bool backward, bool lstm, int n_inst, const int32_t* B, const int32_t* H, const int32_t* want,
-              int* rows_out, int* lds_out) {
+              int* rows_out, int* lds_out, int* sv_stage_out = nullptr) {
     int max_h = 0;
     bool any_auto = false;
     for (int i = 0; i < n_inst; ++i) {
@@ -983,15 +1041,25 @@ int pick_rows(bool backward, bool lstm, int n_inst, const int32_t* B, const int3
             if (rows_out[i] < min_rows) min_rows = rows_out[i];
         }
         const int wv = cand[c].wv16 ? 16 : max_rows / 16;
-        const int lds = lds_bytes_for(backward, lstm, max_h, wv, min_rows);
+        int lds = lds_bytes_for(backward, lstm, max_h, wv, min_rows);
         if (slice_bytes_for(max_h, lstm) > LDS_BUDGET) return 0;
+        // backward, K split: the staged saved values ride along when every instance's own need still fits the CU
+        // (H = 600 in 64-row cells: 117 KB slice + 12 + 24 = 154 KB); else the leads load them themselves
+        int sv_stage = 0;
+        if (backward && cand[c].wv16) {
+            int need = lds;
+            for (int i = 0; i < n_inst; ++i) need = max(need, lds_bytes_staged(lstm, H[i], wv, rows_out[i]));
+            if (need <= LDS_MAX) { lds = need; sv_stage = 1; }
+        }
         const int res = resident_workgroups(backward, lstm, wv, lds);
         static const bool verbose = getenv("DSSVAE_GRU_VERBOSE") != nullptr;
         if (verbose)
-            fprintf(stderr, "[dssvae %s %s] layout %d: rows %d..%d, %d waves, LDS %d B, grid %d, resident %d\n",
-                    lstm ? "lstm" : "gru", backward ? "bwd" : "fwd", c, min_rows, max_rows, wv, lds, wg, res);
+            fprintf(stderr, "[dssvae %s %s] layout %d: rows %d..%d, %d waves, LDS %d B%s, grid %d, resident %d\n",
+                    lstm ? "lstm" : "gru", backward ? "bwd" : "fwd", c, min_rows, max_rows, wv, lds,
+                    sv_stage ? " (saved values staged)" : "", wg, res);
         if (wg <= res) {
             *lds_out = lds;
+            if (sv_stage_out) *sv_stage_out = sv_stage;
             return wv;
         }
     }
@@ -1118,9 +1186,11 @@ extern "C" int dssvae_gru_bwd(const dssvae_gru_bwd_inst* inst, int n_inst, void*
     args.sticky = sticky_word();
     int rows[DSSVAE_GRU_MAX_INST];
     int lds_bytes = 0;
-    const int wv = pick_rows(true, lstm, n_inst, Bs, Hs, want, rows, &lds_bytes);
+    int sv_stage = 0;
+    const int wv = pick_rows(true, lstm, n_inst, Bs, Hs, want, rows, &lds_bytes, &sv_stage);
     if (wv < 0) return DSSVAE_EINVAL;
     if (wv == 0) return DSSVAE_ETOOBIG;
+    args.sv_stage = sv_stage;
     int wg = 0, max_h = 0;
     for (int i = 0; i < n_inst; ++i) {
         BwdDev& d = args.inst[i];
