@@ -836,7 +836,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
                                                                   float* __restrict__ logits, int64_t ldl, int lvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128, LDT = BN + 4;
-    constexpr int TPR = BN / 4, RPP = NTHREADS / TPR, NR = BM / RPP;  // 32 threads per row, 8 rows per pass, 16 passes
+    // 8 threads per row, each with every 8th 16-byte piece of it (4 pieces); 32 rows per pass, 4 passes: 4 running
+    // (max, sum[, arg]) triples per thread live across the mainloop.  (32 threads per row with one piece each carried
+    // 16 triples: with them the kernel needed more than the 256 registers two workgroups per CU leave a wave, and the
+    // 36 spilled ones were reloaded inside the mainloop -- its marginal rate was 116 TFLOP/s against the plain
+    // product's 125 on the same shape.)
+    constexpr int TPR = 8, QPT = BN / 4 / TPR, RPP = NTHREADS / TPR, NR = BM / RPP;
     static_assert(BM * LDT <= lds_floats<false, false, 2, 2>(), "tile image must fit in the operand buffers");
     const int split = blockIdx.x % n_split, mb = blockIdx.x / n_split;
     const int m0 = mb * BM;
@@ -869,44 +874,67 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
                     lds[acc_row<2>(mt, r) * LDT + acc_col<2>(nt)] = ok ? acc[mt][nt][r] + bv : NEG_BIG;
         }
         __syncthreads();
-        const int n = n0 + col;
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int row = rbase + RPP * i;
-            const float4 v = *reinterpret_cast<const float4*>(lds + row * LDT + col);
+            float4 v[QPT];
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) v[q] = *reinterpret_cast<const float4*>(lds + row * LDT + col + 4 * TPR * q);
             const float mo = rm[i];
-            const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
-            const float mn = fmaxf(mo, m4);
-            rs[i] = rs[i] * __expf(mo - mn) + ((__expf(v.x - mn) + __expf(v.y - mn)) + (__expf(v.z - mn) + __expf(v.w - mn)));
+            float m4[QPT];
+#pragma unroll
+            for (int q = 0; q < QPT; ++q) m4[q] = fmaxf(fmaxf(v[q].x, v[q].y), fmaxf(v[q].z, v[q].w));
+            float mt_ = m4[0];
+#pragma unroll
+            for (int q = 1; q < QPT; ++q) mt_ = fmaxf(mt_, m4[q]);
+            const float mn = fmaxf(mo, mt_);
+            float add = 0.f;
+#pragma unroll
+            for (int q = 0; q < QPT; ++q)
+                add += (__expf(v[q].x - mn) + __expf(v[q].y - mn)) + (__expf(v[q].z - mn) + __expf(v[q].w - mn));
+            rs[i] = rs[i] * __expf(mo - mn) + add;
             if (ARG) {
-                if (m4 > mo) ra[i] = n + (v.x == m4 ? 0 : (v.y == m4 ? 1 : (v.z == m4 ? 2 : 3)));
+                if (mt_ > mo) {
+                    // the first (smallest) column that holds the maximum: pieces in ascending column order
+                    int at = 0;
+#pragma unroll
+                    for (int q = QPT - 1; q >= 0; --q)
+                        if (m4[q] == mt_)
+                            at = n0 + col + 4 * TPR * q +
+                                 (v[q].x == mt_ ? 0 : (v[q].y == mt_ ? 1 : (v[q].z == mt_ ? 2 : 3)));
+                    ra[i] = at;
+                }
             }
             rm[i] = mn;
             if (STORE) {
-                // side output: the logits of this row chunk into the cache-resident slab
+                // side output: the logits of this row chunk into the slab
                 const int m = m0 + row;
-                if (m < M && n < N) {
-                    float* c = logits + (int64_t)m * ldl + n;
-                    if (lvec) {
-                        *reinterpret_cast<float4*>(c) = v;
-                    } else {
-                        const float e[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j)
-                            if (n + j < N) c[j] = e[j];
+                for (int q = 0; q < QPT; ++q) {
+                    const int n = n0 + col + 4 * TPR * q;
+                    if (m < M && n < N) {
+                        float* c = logits + (int64_t)m * ldl + n;
+                        if (lvec) {
+                            *reinterpret_cast<float4*>(c) = v[q];
+                        } else {
+                            const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (n + j < N) c[j] = e[j];
+                        }
                     }
                 }
             }
         }
         __syncthreads();  // the image aliases the operand buffers of the next tile
     }
-    // reduce over the 32 lanes that hold the other columns of the same rows, then write the split partials
+    // reduce over the TPR lanes that hold the other columns of the same rows, then write the split partials
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
         float m = rm[i], s = rs[i];
         int ai = ARG ? ra[i] : 0;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
+        for (int o = TPR / 2; o > 0; o >>= 1) {
             const float m2 = __shfl_xor(m, o, 64), s2 = __shfl_xor(s, o, 64);
             const float mn = fmaxf(m, m2);
             s = s * __expf(m - mn) + s2 * __expf(m2 - mn);
