@@ -3,6 +3,8 @@
 Reference quirks that are part of the contract and kept: the tree-decoder head returns a
 per-sentence [B] vector (syntax_vae.py:547-556) so 'MUL Loss' / 'ADV Loss' / 'Loss' are [B]
 vectors; the adversaries run under no_grad in train mode (:322-324)."""
+import os
+
 import torch
 import torch.nn as nn
 
@@ -198,19 +200,28 @@ class TwoEncoderVAE(BaseVAE):
         ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
         # the sentence tokens leave for pinned host memory behind their decode; they are turned into words
         # below while the GPU runs the tree decodes
+        h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
+        n = h_ori.size(1)
+        # The tree decodes (100 steps of three launches that fill a fraction of the chip each) run on a side stream
+        # BESIDE the sentence decode instead of behind it.
+        cur = torch.cuda.current_stream()
+        side = _side_stream(h_ori.device) if os.environ.get("DSSVAE_TRANSFER_STREAMS", "1") != "0" else cur
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            if h_ref.size(1) == n and 2 * n <= 128:
+                # the two tree decodes are launch-bound and independent row by row: one decode of 2B rows
+                # (still within the decode-batch kernels' 128 rows, so every row sees the same arithmetic)
+                tree_tokens = [predictor.predict(torch.cat((h_ori, h_ref), dim=1))]
+            else:
+                tree_tokens = [predictor.predict(h_ori), predictor.predict(h_ref)]
         sent_dev = self.decode_tokens(ret).t()
         sent_tokens = torch.empty(sent_dev.shape, dtype=sent_dev.dtype, pin_memory=True)
         sent_tokens.copy_(sent_dev, non_blocking=True)
         sent_done = torch.cuda.Event()
         sent_done.record()
-        h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
-        n = h_ori.size(1)
-        if h_ref.size(1) == n and 2 * n <= 128:
-            # the two 100-step tree decodes are launch-bound and independent row by row: one decode of 2B rows
-            # (still within the decode-batch kernels' 128 rows, so every row sees the same arithmetic)
-            tree_tokens = [predictor.predict(torch.cat((h_ori, h_ref), dim=1))]
-        else:
-            tree_tokens = [predictor.predict(h_ori), predictor.predict(h_ref)]
+        cur.wait_stream(side)
+        for t in tree_tokens:
+            t.record_stream(cur)
         sent_done.synchronize()
         ret["res"] = self._words(sent_tokens, self.vocab.src)
         trees = [t for tok in tree_tokens for t in self._words(tok.t(), self.vocab.tgt)]
@@ -225,6 +236,16 @@ class TwoEncoderVAE(BaseVAE):
             res = id2word(hyp, vocab)
             out.append([[res], [len(res)]])
         return out
+
+
+_SIDE = {}
+
+
+def _side_stream(dev):
+    key = torch.device(dev).index
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
 
 
 class SyntaxVAE(TwoEncoderVAE):
