@@ -191,6 +191,17 @@ def generate_bench(a, model, vocab, margs, rank, world, margs_dict=None):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["prior_sampling"] = {"sentences": len(res), "seconds": dt, "sentences_per_s": len(res) / dt}
+        if bs != 1000:
+            # the same sampling at eval_bs 1000 (the large decode batch: tiled GEMM + LSE kernels instead of the
+            # decode-batch kernels), reported beside the reference's default batch
+            model.generating(1000, 1000)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            res_big = model.generating(max(n, 1000), 1000)
+            torch.cuda.synchronize()
+            dt_big = time.perf_counter() - t0
+            out["prior_sampling_eval_bs_1000"] = {"sentences": len(res_big), "seconds": dt_big,
+                                                  "sentences_per_s": len(res_big) / dt_big}
         tot_ms, launches = C.c_double(0.0), C.c_int(0)
         if not a.no_kernel_events:
             lib.dssvae_decode_profile(1)  # HIP events around every projection + arg-max launch
