@@ -632,7 +632,13 @@ def _pick_split(M, N):
     """column splits of the LSE kernel: about two workgroups per CU (its occupancy); the kernel deals the
     128-column tiles evenly over the splits (no split more than one tile longer than another)"""
     tiles_m, tiles_n = (M + 127) // 128, (N + 127) // 128
-    return max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
+    S = max(1, min(tiles_n, (2 * n_cus()) // tiles_m, 128))
+    # a few column tiles and many row blocks (the tree heads: 3 tiles x 182 row blocks): one tile per workgroup even
+    # when that is a little more than a round of the chip -- two splits of 2 + 1 tiles leave half the workgroups with
+    # twice the work
+    if S < tiles_n <= 4 and tiles_m * tiles_n <= 3 * n_cus() and _os.environ.get("DSSVAE_LSE_EVEN", "1") != "0":
+        S = tiles_n
+    return S
 
 
 def _one_panel(xh, xe):

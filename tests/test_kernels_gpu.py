@@ -77,6 +77,43 @@ def test_gemm_grouped_and_linear_many():
     close(b1.grad, leaves[1][2].grad, rtol=1e-4, atol=1e-5, what="many db1")
 
 
+@pytest.mark.parametrize("kind,shapes", [
+    ("tn", [(450, 150, 7680)] * 4),                                      # the encoder's recurrent weight gradients
+    ("tn", [(133, 70, 5000), (450, 300, 7681), (64, 900, 4000)]),        # narrow, narrow, wide + remainder; K tails
+    ("nt", [(200, 140, 20000), (90, 1000, 9000)]),                       # with a bias: added by the piece that holds k = 0
+    ("nn", [(257, 130, 24000)]),
+])
+def test_gemm_grouped_stream_k_form(kind, shapes):
+    """grouped launches with few output tiles and long K run in the stream-K form (whole tiles as plain stores, pieces as
+    atomics into the zero-filled output): against fp64, and against the tile-per-workgroup form of the same launch"""
+    import os
+    from dss_vae_amd import ops
+    pairs, refs, biases = [], [], []
+    for i, (M, N, K) in enumerate(shapes):
+        if kind == "nt":
+            a, b = rnd(M, K, seed=i), rnd(N, K, seed=50 + i)
+            ref = a.double() @ b.double().t()
+        elif kind == "nn":
+            a, b = rnd(M, K, seed=i), rnd(K, N, seed=50 + i)
+            ref = a.double() @ b.double()
+        else:
+            a, b = rnd(K, M, seed=i), rnd(K, N, seed=50 + i)
+            ref = a.double().t() @ b.double()
+        bias = rnd(N, seed=90 + i) if kind == "nt" else None
+        pairs.append((a.to(DEV), b.to(DEV)))
+        biases.append(None if bias is None else bias.to(DEV))
+        refs.append(ref if bias is None else ref + bias.double())
+    kw = dict(biases=biases) if kind == "nt" else {}
+    outs = {}
+    for sk in ("1", "0"):
+        os.environ["DSSVAE_GROUP_SK"] = sk
+        outs[sk] = [o.clone() for o in ops._gemm_grouped(kind, pairs, **kw)]
+    os.environ.pop("DSSVAE_GROUP_SK", None)
+    for got, other, ref in zip(outs["1"], outs["0"], refs):
+        close(got, ref, rtol=1e-4, atol=2e-5, what="stream-K " + kind)
+        close(other, ref, rtol=1e-4, atol=2e-5, what="tiles " + kind)
+
+
 def test_gemm_row_gather():
     from dss_vae_amd import ops
     tab, w = rnd(50, 24, seed=1).to(DEV), rnd(36, 24, seed=2).to(DEV)
