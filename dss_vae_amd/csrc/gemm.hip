@@ -874,6 +874,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
                     lds[acc_row<2>(mt, r) * LDT + acc_col<2>(nt)] = ok ? acc[mt][nt][r] + bv : NEG_BIG;
         }
         __syncthreads();
+#ifdef LSE_DEV_NOEPI  // development build: the tiles without their row statistics and slab stores (results are garbage)
+        if (n0 < 0)
+#endif
 #pragma unroll
         for (int i = 0; i < NR; ++i) {
             const int row = rbase + RPP * i;
@@ -906,7 +909,11 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
                 }
             }
             rm[i] = mn;
+#ifdef LSE_DEV_NOSLAB  // development build: statistics only, no slab stores
+            if (STORE && n0 < 0) {
+#else
             if (STORE) {
+#endif
                 // side output: the logits of this row chunk into the slab
                 const int m = m0 + row;
 #pragma unroll
@@ -915,7 +922,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
                     if (m < M && n < N) {
                         float* c = logits + (int64_t)m * ldl + n;
                         if (lvec) {
-                            *reinterpret_cast<float4*>(c) = v[q];
+                            // streaming store: the slab (1 GB) is written once and read by other kernels; kept out
+                            // of the L2 it would otherwise sweep the operand tiles from (+1.3 % at K = 900)
+                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v[q]), reinterpret_cast<f32x4*>(c));
                         } else {
                             const float e[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
