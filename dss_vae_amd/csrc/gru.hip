@@ -808,7 +808,9 @@ __global__ __launch_bounds__(64 * WV) void gru_bwd_kernel(BwdArgs args) {
             };
             if (fast4s) {
                 if (row_ok && ub + 4 <= H)
-                    store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x4*>(q) = (f32x4){v[0], v[1], v[2], v[3]}; });
+                    store_all([](float* q, const float (&v)[4]) {   // streaming: read next by a GEMM, not by this launch
+                        __builtin_nontemporal_store((f32x4){v[0], v[1], v[2], v[3]}, reinterpret_cast<f32x4*>(q));
+                    });
             } else if (fast2s) {
                 if (row_ok && ub + 2 <= H)
                     store_all([](float* q, const float (&v)[4]) { *reinterpret_cast<f32x2*>(q) = (f32x2){v[0], v[1]}; });
