@@ -266,7 +266,31 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g, 
     float clip = 1.f;
     if (sumsq && max_norm > 0.f) clip = fminf(1.f, max_norm / (sqrtf(sumsq[0]) + 1e-6f));
     const float step = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    int64_t done = 0;
+    // 16-byte granules when the four arrays allow it (the flat buffers' slots are 16-byte aligned): same arithmetic per
+    // element, a quarter of the memory instructions
+    if (!live && (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15u) == 0) {
+        const int64_t n4 = n >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+            const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+            float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+            float* gp = (float*)&g4; float* mp = (float*)&m4; float* vp = (float*)&v4; float* pp = (float*)&p4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float gi = gp[c] * clip;
+                const float mi = b1 * mp[c] + (1.f - b1) * gi;
+                const float vi = b2 * vp[c] + (1.f - b2) * gi * gi;
+                mp[c] = mi;
+                vp[c] = vi;
+                pp[c] -= step * mi / (sqrtf(vi) / bc2_sqrt + eps);
+            }
+            reinterpret_cast<float4*>(m)[i] = m4;
+            reinterpret_cast<float4*>(v)[i] = v4;
+            reinterpret_cast<float4*>(p)[i] = p4;
+        }
+        done = n4 << 2;
+    }
+    for (int64_t i = done + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         if (live && live[i] == 0.f) continue;  // parameter had no gradient this step: Adam skips it
         const float gi = g[i] * clip;
         const float mi = b1 * m[i] + (1.f - b1) * gi;
