@@ -40,7 +40,8 @@ struct OpA {
     // LDS image is the softmax part of dlogits, coef * exp(logit - lse) = exp2(logit * log2(e) - l2), computed
     // while the tile is staged from ONE float per slab row: l2 = (lse - ln coef) * log2(e)  (+inf where coef = 0).
     // The one-hot part of dlogits is a rank-one-per-row correction of the products (ce_onehot_fixup_kernel).
-    const float* xf;
+    const float* xf;   // XF: per (128-column tile, row) scale of the normalised slab, [tile][xf_ld]
+    int64_t xf_ld;
 };
 struct OpB {
     const float* p; int64_t ld;
@@ -83,7 +84,8 @@ struct Stager {
     unsigned okmask;  // which staged registers hold in-range k (the k tail is zeroed when written to LDS)
 
     __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int K1_, const float* p2_, int64_t ld2_,
-                                         const int64_t* rows_, int Rtot_, int r0_, int K_, const float* xf_ = nullptr) {
+                                         const int64_t* rows_, int Rtot_, int r0_, int K_, const float* xf_ = nullptr,
+                                         int64_t = 0) {
         xf = xf_;
         xf_vec = (reinterpret_cast<uintptr_t>(xf_) & 15u) == 0;
         p1 = p1_; ld1 = ld1_; K1 = K1_; p2 = p2_ ? p2_ : p1_; ld2 = p2_ ? ld2_ : ld1_; rows = rows_;
@@ -107,14 +109,12 @@ struct Stager {
         return XF ? NV * (int)(threadIdx.x / TPK) + i : (int)(threadIdx.x / TPK) + KSTEP * i;
     }
 
-    // softmax part of dlogits for one granule of a slab row: two VALU instructions per element (v_fma, v_exp)
-    static __device__ __forceinline__ float4 dlogits(float4 x, float l2) {
-        constexpr float LOG2E = 1.4426950408889634f;
+    // softmax part of dlogits for one granule of a slab row.  The slab holds exp(x - max of the row in its 128-column
+    // tile) (the LSE kernel wrote it so) and `s` = coef * exp(that max - lse): one multiply per element, where raw
+    // logits cost a v_fma and a v_exp each -- and every VALU instruction between MFMAs costs matrix time
+    static __device__ __forceinline__ float4 dlogits(float4 x, float s) {
         float4 o;
-        o.x = __builtin_amdgcn_exp2f(__builtin_fmaf(x.x, LOG2E, -l2));
-        o.y = __builtin_amdgcn_exp2f(__builtin_fmaf(x.y, LOG2E, -l2));
-        o.z = __builtin_amdgcn_exp2f(__builtin_fmaf(x.z, LOG2E, -l2));
-        o.w = __builtin_amdgcn_exp2f(__builtin_fmaf(x.w, LOG2E, -l2));
+        o.x = x.x * s; o.y = x.y * s; o.z = x.z * s; o.w = x.w * s;
         return o;
     }
 
@@ -294,7 +294,9 @@ struct FastStager {
     static constexpr bool MASK_FREE = true;   // load_part<false> / store_part<false> keep no per-tile state
     static_assert(!XF || (NV == 4 && (!TRANS || KSTEP * NV == BK)), "the dlogits stagers are written for 128-row tiles");
     float4 v[NV];
-    float ri[XF ? NV : 1];    // l2 of the slab rows of the staged granules (XF)
+    float ri[XF ? NV : 1];    // scale of the staged granules' (slab row, column tile) (XF)
+    uint32_t rowi[(XF && !TRANS) ? NV : 1];   // slab row of granule i (XF, not transposed: fixed for the tile loop)
+    int64_t xf_ld;
     uint32_t off[NV];         // byte offset of granule i from the tile's base address
     uint32_t st;              // float offset of granule 0 in the LDS image
     const float* p; const float* xf;
@@ -309,16 +311,18 @@ struct FastStager {
     static constexpr __host__ __device__ bool in_part(int i, int part) { return (i * 4) / NV == part; }
 
     __device__ __forceinline__ void init(const float* p1_, int64_t ld1_, int, const float*, int64_t, const int64_t*,
-                                         int Rtot, int r0, int K_, const float* xf_ = nullptr) {
-        p = p1_; ld = ld1_; K = K_; xf = xf_; okmask = ~0u; lk0 = 0;
-        xf_vec = (reinterpret_cast<uintptr_t>(xf_) & 15u) == 0;
+                                         int Rtot, int r0, int K_, const float* xf_ = nullptr, int64_t xf_ld_ = 0) {
+        p = p1_; ld = ld1_; K = K_; xf = xf_; okmask = ~0u; lk0 = 0; xf_ld = xf_ld_;
+        // transposed (wgrad): the tile's rows ARE one 128-column tile of the slab; its scales are a vector over k
+        if (XF && TRANS) xf = xf_ + (int64_t)(r0 >> 7) * xf_ld_;
+        xf_vec = (reinterpret_cast<uintptr_t>(xf) & 15u) == 0;
         if (!TRANS) {
             st = (threadIdx.x / TPR) * LDK + 4 * (threadIdx.x % TPR);
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int r = min(r0 + (int)(threadIdx.x / TPR) + RPP * i, Rtot - 1);
                 off[i] = (uint32_t)(((int64_t)r * ld + 4 * (int)(threadIdx.x % TPR)) * 4);
-                if (XF) ri[i] = xf[r];   // the slab rows of this thread's granules never change
+                if constexpr (XF) rowi[i] = (uint32_t)r;   // the slab rows of this thread's granules never change
             }
         } else {
             const int rv = min(r0 + 4 * (int)(threadIdx.x % TPK), Rtot - 4);
@@ -344,6 +348,13 @@ struct FastStager {
 #pragma unroll
             for (int i = 0; i < NV; ++i)
                 if (in_part(i, part)) v[i] = *reinterpret_cast<const float4*>(base + off[i]);
+            if constexpr (XF && !TRANS) {
+                if (part == 3) {   // the scales of this k-tile's column tile (k = slab column; 32 | 128)
+                    const float* t = xf + (int64_t)(lk0 >> 7) * xf_ld;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) ri[i] = t[rowi[i]];
+                }
+            }
             if constexpr (XF && TRANS) {
                 if (part == 3) {   // (behind the last transform of the tile whose records these registers still hold)
                     if (xf_vec) {
@@ -364,6 +375,13 @@ struct FastStager {
             for (int i = 0; i < NV; ++i)
                 if (in_part(i, part))
                     v[i] = *reinterpret_cast<const float4*>(ok ? base + off[i] : reinterpret_cast<const char*>(p) + (off[i] - 4 * kc));
+            if constexpr (XF) {
+                if (part == 0) {
+                    const float* t = xf + (int64_t)(min(lk0, K - 1) >> 7) * xf_ld;
+#pragma unroll
+                    for (int i = 0; i < NV; ++i) ri[i] = t[rowi[i]];
+                }
+            }
         } else {
             if (part == 0) okmask = 0u;
 #pragma unroll
@@ -474,12 +492,12 @@ __device__ __forceinline__ void k_tile(SA& sa, SB& sb, float* As, float* Bs, int
                 sa.template store_part<TAIL>(An, jj);
                 sb.template store_part<TAIL>(Bn, jj);
                 if constexpr (XF) {
-                    // one granule's transform (4 x {v_fma, v_exp}) rides between this sub-step's MFMAs instead of
+                    // one granule's transform (4 multiplies) rides between this sub-step's MFMAs instead of
                     // queueing behind the last one
 #pragma unroll
                     for (int q = 0; q < WM * WN; ++q) {
                         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
-                        __builtin_amdgcn_sched_group_barrier(0x002, (8 + WM * WN - 1) / (WM * WN), 0);  // VALU
+                        __builtin_amdgcn_sched_group_barrier(0x002, (4 + WM * WN - 1) / (WM * WN), 0);  // VALU
                     }
                 }
             }
@@ -532,7 +550,7 @@ __device__ __forceinline__ void tile_mainloop(const OpA& a, const OpB& b, int M,
 
     typename StagerOf<TA, VW, BM, XF>::T sa;
     typename StagerOf<TB, VW, BN, false>::T sb;
-    sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K, XF ? a.xf : nullptr);
+    sa.init(a.p1, a.ld1, a.K1, a.p2, a.ld2, a.rows, M, m0, K, XF ? a.xf : nullptr, XF ? a.xf_ld : 0);
     sb.init(b.p, b.ld, K, nullptr, 0, nullptr, N, n0, K);
 
     // Rotated software pipeline.  Per k-tile: NG groups of 8 k (4 MFMAs per 32x32 tile each); the
@@ -703,13 +721,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_store_kernel(OpA a, OpB b, floa
                                              cvec, wid, lds);
 }
 
-// l2 of one slab row for the XF stagers: coef * exp(x - lse) = exp2(x * log2(e) - l2)
-__global__ void ce_rowinfo_kernel(const float* __restrict__ lse, const float* __restrict__ coef, int M,
-                                  float* __restrict__ out) {
+// scale of (128-column tile t, slab row m) for the XF stagers: the slab holds exp(x - tile_max[t][m]), the softmax part of
+// dlogits is coef * exp(x - lse) = slab * coef * exp(tile_max - lse); in place over the table the LSE kernel filled
+__global__ void ce_rowscale_kernel(const float* __restrict__ lse, const float* __restrict__ coef, int M, int tiles,
+                                   float* __restrict__ tab, int64_t ld) {
     const int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
-    const float c = coef[m];
-    out[m] = c > 0.f ? (lse[m] - __logf(c)) * 1.4426950408889634f : __builtin_inff();
+    const float c = coef[m], l = lse[m];
+    for (int t = blockIdx.y; t < tiles; t += gridDim.y) {
+        float* q = tab + (int64_t)t * ld + m;
+        *q = c > 0.f ? c * __expf(*q - l) : 0.f;
+    }
 }
 
 // One-hot part of dlogits, dL[m, target[m]] -= w, as corrections of the two products (one wave per slab row):
@@ -772,7 +794,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_kernel(GroupArgs g) {
     while (i + 1 < g.n && bid >= g.p[i + 1].wg_begin) ++i;
     const GroupProblem& q = g.p[i];
     OpA a;
-    a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr;
+    a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr; a.xf_ld = 0;
     OpB b;
     b.p = q.B; b.ld = q.ldb;
     const int wid = bid - q.wg_begin;
@@ -802,7 +824,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_sk_kernel(GroupArgs g) {
         const int f_hi = min((max(hi - q.unit_begin, 0) + w - 1) / w, total);
         if (f >= f_hi) continue;
         OpA a;
-        a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr;
+        a.p1 = q.A; a.ld1 = q.lda; a.K1 = q.K; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr; a.xf = nullptr; a.xf_ld = 0;
         OpB b;
         b.p = q.B; b.ld = q.ldb;
         while (f < f_hi) {
@@ -828,13 +850,17 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_sk_kernel(GroupArgs g) {
 // instead of one per accumulator row (32 per lane): the kernel fits 2 waves per SIMD (two
 // workgroups per CU), which is what hides the epilogue and the barrier skew behind the other
 // workgroup's MFMAs.  One 32-lane shuffle reduction per row at the very end.
-template <bool ARG, int VW, bool STORE>
+// STORE: 0 = statistics only; 1 = + the logits of the row chunk into the slab; 2 = + the slab NORMALISED per 128-column
+// tile: exp(x - max of the row within the tile), and that maximum into tile_max[tile][row] -- what the gradient GEMMs
+// (dssvae_gemm_f32_dlogits) multiply by one scale per (row, tile) while they stage it
+template <bool ARG, int VW, int STORE>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
                                                                   int N, int K, int n_split, int tiles_per_split,
                                                                   int tiles_n, float* __restrict__ part_max,
                                                                   float* __restrict__ part_sum,
                                                                   int64_t* __restrict__ part_arg,
-                                                                  float* __restrict__ logits, int64_t ldl, int lvec) {
+                                                                  float* __restrict__ logits, int64_t ldl, int lvec,
+                                                                  float* __restrict__ tile_max, int64_t ldt) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128, LDT = BN + 4;
     // 8 threads per row, each with every 8th 16-byte piece of it (4 pieces); 32 rows per pass, 4 passes: 4 running
@@ -891,6 +917,34 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
             float mt_ = m4[0];
 #pragma unroll
             for (int q = 1; q < QPT; ++q) mt_ = fmaxf(mt_, m4[q]);
+            if constexpr (STORE == 2) {
+                // the row's maximum within this tile: over the TPR lanes that hold the row's other pieces
+                float mr = mt_;
+#pragma unroll
+                for (int o = TPR / 2; o > 0; o >>= 1) mr = fmaxf(mr, __shfl_xor(mr, o, 64));
+                const float mn2 = fmaxf(mo, mr);
+                float add2 = 0.f;
+#pragma unroll
+                for (int q = 0; q < QPT; ++q) {
+                    v[q].x = __expf(v[q].x - mr); v[q].y = __expf(v[q].y - mr);
+                    v[q].z = __expf(v[q].z - mr); v[q].w = __expf(v[q].w - mr);
+                    add2 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
+                }
+                rs[i] = rs[i] * __expf(mo - mn2) + add2 * __expf(mr - mn2);
+                rm[i] = mn2;   // (the same in all lanes of the row: every tile's maximum is shared)
+                const int m = m0 + row;
+                if (m < M) {
+                    if ((threadIdx.x % TPR) == 0) tile_max[(int64_t)tn * ldt + m] = mr;
+#pragma unroll
+                    for (int q = 0; q < QPT; ++q) {
+                        const int n = n0 + col + 4 * TPR * q;
+                        if (n < N)   // (ldl and N are multiples of 4 in this mode: the host checks)
+                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v[q]),
+                                                        reinterpret_cast<f32x4*>(logits + (int64_t)m * ldl + n));
+                    }
+                }
+                continue;
+            }
             const float mn = fmaxf(mo, mt_);
             float add = 0.f;
 #pragma unroll
@@ -911,9 +965,9 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
             }
             rm[i] = mn;
 #ifdef LSE_DEV_NOSLAB  // development build: statistics only, no slab stores
-            if (STORE && n0 < 0) {
+            if (STORE == 1 && n0 < 0) {
 #else
-            if (STORE) {
+            if (STORE == 1) {
 #endif
                 // side output: the logits of this row chunk into the slab
                 const int m = m0 + row;
@@ -1204,7 +1258,7 @@ int operand_vw(const float* p, int64_t ld, bool trans, int rows, int K) {
 
 OpA make_panels(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, bool* vec) {
     OpA a;
-    a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr; a.xf = nullptr;
+    a.p1 = Xh; a.ld1 = ldh; a.K1 = Kh; a.p2 = Ke > 0 ? Xe : nullptr; a.ld2 = lde; a.rows = nullptr; a.xf = nullptr; a.xf_ld = 0;
     *vec = vec_ok(Xh, ldh) && (Ke == 0 || vec_ok(Xe, lde)) && (Kh % 4 == 0) && (Ke % 4 == 0);
     return a;
 }
@@ -1330,7 +1384,7 @@ extern "C" int dssvae_gemm_f32_splitk(const float* A, int64_t lda, int trans_a, 
     if ((trans_a ? lda < M : lda < K) || (trans_b ? ldb < N : ldb < K)) return DSSVAE_EINVAL;
     if (M == 0 || N == 0) return DSSVAE_OK;
     OpA a;
-    a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows; a.xf = nullptr;
+    a.p1 = A; a.ld1 = lda; a.K1 = K; a.p2 = nullptr; a.ld2 = 0; a.rows = a_rows; a.xf = nullptr; a.xf_ld = 0;
     OpB b;
     b.p = B; b.ld = ldb;
     // widest granule both operands allow: every granule is aligned and entirely in or out of range
@@ -1487,12 +1541,14 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
 #undef GO
 }
 
-extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
-                                     const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
-                                     float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
-                                     float* logits, int64_t ldl, void* stream) {
+static int lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, const float* W,
+                   int64_t ldw, const float* bias, int M, int N, int n_split, float* part_max, float* part_sum,
+                   int64_t* part_arg, int want_argmax, float* logits, int64_t ldl, float* tile_max, int64_t ldt,
+                   void* stream) {
     if (!Xh || !W || !part_max || !part_sum || M <= 0 || N <= 0 || Kh <= 0 || Ke < 0 || n_split <= 0)
         return DSSVAE_EINVAL;
+    // the normalised slab leaves as 16-byte pieces only
+    if (tile_max && (!logits || ldt < M || !aligned16(logits) || (ldl % 4) != 0 || (N % 4) != 0)) return DSSVAE_EINVAL;
     if (Ke > 0 && !Xe) return DSSVAE_EINVAL;
     if (want_argmax && !part_arg) return DSSVAE_EINVAL;
     if (logits && (ldl < N || want_argmax)) return DSSVAE_EINVAL;
@@ -1515,19 +1571,37 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
         allow_lds(linear_lse_kernel<ARG, VW, ST>, lds_bytes);                                                     \
         hipLaunchKernelGGL((linear_lse_kernel<ARG, VW, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes,  \
                            s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg,     \
-                           logits, ldl, lvec);                                                                    \
+                           logits, ldl, lvec, tile_max, ldt);                                                     \
     } while (0)
 #define GO(ARG, ST)                                                                                               \
     do {                                                                                                          \
         if (vw == 4) GO1(ARG, 4, ST); else if (vw == 2) GO1(ARG, 2, ST); else GO1(ARG, 1, ST);                    \
     } while (0)
-    if (logits) GO(false, true);
-    else if (want_argmax) GO(true, false);
-    else GO(false, false);
+    if (logits && tile_max) GO(false, 2);
+    else if (logits) GO(false, 1);
+    else if (want_argmax) GO(true, 0);
+    else GO(false, 0);
 #undef GO
 #undef GO1
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
+}
+
+extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                                     const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
+                                     float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
+                                     float* logits, int64_t ldl, void* stream) {
+    return lse_fwd(Xh, ldh, Kh, Xe, lde, Ke, W, ldw, bias, M, N, n_split, part_max, part_sum, part_arg, want_argmax,
+                   logits, ldl, nullptr, 0, stream);
+}
+
+extern "C" int dssvae_linear_lse_fwd_norm(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                                          const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
+                                          float* part_max, float* part_sum, float* slab, int64_t ldl,
+                                          float* tile_max, int64_t ldt, void* stream) {
+    if (!slab || !tile_max) return DSSVAE_EINVAL;
+    return lse_fwd(Xh, ldh, Kh, Xe, lde, Ke, W, ldw, bias, M, N, n_split, part_max, part_sum, nullptr, 0, slab, ldl,
+                   tile_max, ldt, stream);
 }
 
 extern "C" int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg, int M,
@@ -1616,10 +1690,11 @@ extern "C" int dssvae_colsum(const float* X, int64_t ldx, int M, int N, float* o
     return DSSVAE_OK;
 }
 
-extern "C" int dssvae_ce_rowinfo(const float* lse, const float* coef, int M, float* rowinfo, void* stream) {
-    if (!lse || !coef || !rowinfo || M <= 0) return DSSVAE_EINVAL;
-    hipLaunchKernelGGL(ce_rowinfo_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, lse, coef, M,
-                       rowinfo);
+extern "C" int dssvae_ce_rowscale(const float* lse, const float* coef, int M, int tiles, float* table, int64_t ld,
+                                  void* stream) {
+    if (!lse || !coef || !table || M <= 0 || tiles <= 0 || ld < M) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(ce_rowscale_kernel, dim3((M + 255) / 256, tiles < 64 ? tiles : 64), dim3(256), 0,
+                       (hipStream_t)stream, lse, coef, M, tiles, table, ld);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -1636,10 +1711,12 @@ extern "C" int dssvae_ce_onehot_fixup(const int64_t* target, int64_t ignore_inde
     return DSSVAE_OK;
 }
 
-extern "C" int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int rows, int cols, const float* rowinfo,
-                                       int trans_a, const float* B, int64_t ldb, float* C, int64_t ldc, int N,
-                                       float beta, void* stream) {
-    if (!logits || !rowinfo || !B || !C || rows <= 0 || cols <= 0 || N <= 0 || ldl < cols || ldb < N || ldc < N)
+extern "C" int dssvae_gemm_f32_dlogits(const float* slab, int64_t ldl, int rows, int cols, const float* scale,
+                                       int64_t ld_scale, int trans_a, const float* B, int64_t ldb, float* C,
+                                       int64_t ldc, int N, float beta, void* stream) {
+    const float* logits = slab;
+    if (!logits || !scale || !B || !C || rows <= 0 || cols <= 0 || N <= 0 || ldl < cols || ldb < N || ldc < N ||
+        ld_scale < rows)
         return DSSVAE_EINVAL;
     if (beta != 0.f && beta != 1.f) return DSSVAE_EINVAL;
     // 16-byte granules everywhere: the caller falls back to dssvae_softmax_grad_inplace + dssvae_gemm_f32 otherwise
@@ -1649,7 +1726,7 @@ extern "C" int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int row
         return DSSVAE_ETOOBIG;
     OpA a;
     a.p1 = logits; a.ld1 = ldl; a.p2 = nullptr; a.ld2 = 0; a.rows = nullptr;
-    a.xf = rowinfo;
+    a.xf = scale; a.xf_ld = ld_scale;
     OpB b;
     b.p = B; b.ld = ldb;
     hipStream_t s = (hipStream_t)stream;

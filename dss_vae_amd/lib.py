@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 7  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 8  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -72,9 +72,10 @@ _SIGNATURES = {
     "dssvae_gemm_f32_grouped": ([C.POINTER(GemmProblem), _I, _I, _I, _P], _I),
     "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_softmax_grad_inplace": ([_P, _L, _P, _P, _I, _I, _P, _P], _I),
-    "dssvae_ce_rowinfo": ([_P, _P, _I, _P, _P], _I),
+    "dssvae_ce_rowscale": ([_P, _P, _I, _I, _P, _L, _P], _I),
+    "dssvae_linear_lse_fwd_norm": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P], _I),
     "dssvae_ce_onehot_fixup": ([_P, _L, _P, _I, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P], _I),
-    "dssvae_gemm_f32_dlogits": ([_P, _L, _I, _I, _P, _I, _P, _L, _P, _L, _I, _F, _P], _I),
+    "dssvae_gemm_f32_dlogits": ([_P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _L, _I, _F, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "dssvae_picked_logit": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _I, _P, _P], _I),
     "dssvae_linear_ce_dlogits": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _P, _I, _I, _P, _L, _P, _P], _I),

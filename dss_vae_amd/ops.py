@@ -310,13 +310,13 @@ def _gemm_grouped(kind, pairs, biases=None, outs_given=None):
     return outs
 
 
-def _gemm_dlogits(slab, ldl, rows, cols, rowinfo, trans_a, B, ldb, Cm, ldc, N, beta):
+def _gemm_dlogits(slab, ldl, rows, cols, scale, trans_a, B, ldb, Cm, ldc, N, beta):
     """C (+)= dlogits(slab) . B or dlogits(slab)^T . B with the softmax gradient applied while the slab is staged"""
     M_, K_ = (cols, rows) if trans_a else (rows, cols)
     with _Span("gemm_store_kernel", 2.0 * M_ * N * K_, 4.0 * (M_ * K_ + N * K_ + M_ * N),
                detail="%s dlogits M=%d N=%d K=%d%s" % ("tn" if trans_a else "nn", M_, N, K_, " +=" if beta else "")) as sp:
-        L.check(L.load().dssvae_gemm_f32_dlogits(L.ptr(slab), ldl, rows, cols, L.ptr(rowinfo), int(trans_a), L.ptr(B),
-                                                 ldb, L.ptr(Cm), ldc, N, float(beta), L.stream()),
+        L.check(L.load().dssvae_gemm_f32_dlogits(L.ptr(slab), ldl, rows, cols, L.ptr(scale), scale.stride(0),
+                                                 int(trans_a), L.ptr(B), ldb, L.ptr(Cm), ldc, N, float(beta), L.stream()),
                 "dssvae_gemm_f32_dlogits")
         if PROFILE is not None:
             sp.launches = L.load().dssvae_gemm_last_launches()
@@ -647,7 +647,9 @@ def _one_panel(xh, xe):
     return torch.cat((xh, xe), dim=1)
 
 
-def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None):
+def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None, tile_max=None):
+    """tile_max ([ceil(N / 128), >= M] floats): `logits` receives the slab normalised per 128-column tile and the
+    table the tiles' row maxima (dssvae_linear_lse_fwd_norm) instead of raw logits"""
     if xe is not None and Ke > 0 and (Kh + Ke) % 4 == 0:
         xh, xe = _one_panel(xh[:M], xe[:M]), None
         ldh, Kh, lde, Ke = xh.stride(0), Kh + Ke, 0, 0
@@ -659,10 +661,16 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None,
     lib = L.load()
     with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S),
                detail="M=%d N=%d K=%d+%d S=%d%s" % (M, N, Kh, Ke, S, " store" if logits is not None else "")):
-        L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
-                                          L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
-                                          0 if logits is None else logits.stride(0), L.stream()),
-                "dssvae_linear_lse_fwd")
+        if tile_max is not None:
+            L.check(lib.dssvae_linear_lse_fwd_norm(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N,
+                                                   S, L.ptr(pm), L.ptr(ps), L.ptr(logits), logits.stride(0),
+                                                   L.ptr(tile_max), tile_max.stride(0), L.stream()),
+                    "dssvae_linear_lse_fwd_norm")
+        else:
+            L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
+                                              L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
+                                              0 if logits is None else logits.stride(0), L.stream()),
+                    "dssvae_linear_lse_fwd")
     lse = torch.empty(M, device=dev, dtype=torch.float32) if lse_out is None else lse_out
     arg = torch.empty(M, device=dev, dtype=torch.int64) if want_arg else None
     L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, L.ptr(lse), L.ptr(arg), L.stream()),
@@ -783,7 +791,9 @@ class _LinearCEFn(Function):
             dWp = torch.empty(N, Kw, device=dev, dtype=torch.float32) if need_w else None
             db = torch.zeros(N, device=dev, dtype=torch.float32) if (need_b and not fuse) else None
             ones = None if fuse else torch.ones(M, T, device=dev, dtype=torch.float32)
-            rowinfo = torch.empty(M, device=dev, dtype=torch.float32) if fuse else None
+            # per stream-slab: the row maxima of every 128-column tile of the chunk, turned into the stagers' scales
+            tabs = [torch.empty((N + 127) // 128, min(mc, M), device=dev, dtype=torch.float32) if fuse else None
+                    for _ in range(n_str)]
             xcat = None
             if need_w or xe is not None:   # (one activation panel for the projection kernels as well: _one_panel)
                 parts = [xh] if xe is None else [xh, xe]
@@ -806,17 +816,18 @@ class _LinearCEFn(Function):
                 st = streams[ci % n_str]
                 with torch.cuda.stream(st):
                     dl = slabs[ci % n_str][:rows]
+                    tab = tabs[ci % n_str]
                     if xe is not None:   # [h | e (| 1 0 0 0)] is one matrix already: its first K columns
                         _lse(xcat[m0:m0 + rows], xcat.stride(0), K, None, 0, 0, W, ldw, b, rows, N, logits=dl,
-                             lse_out=lse[m0:m0 + rows])
+                             lse_out=lse[m0:m0 + rows], tile_max=tab)
                     else:
                         _lse(xh[m0:m0 + rows], ldh, Kh, None, 0, 0, W, ldw, b, rows, N, logits=dl,
-                             lse_out=lse[m0:m0 + rows])
+                             lse_out=lse[m0:m0 + rows], tile_max=tab)
                     if fuse:
-                        L.check(lib.dssvae_ce_rowinfo(L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, L.ptr(rowinfo[m0:]),
-                                                      L.stream()), "dssvae_ce_rowinfo")
+                        L.check(lib.dssvae_ce_rowscale(L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows, tab.size(0), L.ptr(tab),
+                                                       tab.stride(0), L.stream()), "dssvae_ce_rowscale")
                         if need_x:
-                            _gemm_dlogits(dl, ldd, rows, N, rowinfo[m0:], 0, W[:, kx0:kx1], ldw, dx[m0:m0 + rows],
+                            _gemm_dlogits(dl, ldd, rows, N, tab, 0, W[:, kx0:kx1], ldw, dx[m0:m0 + rows],
                                           dx.stride(0), kx1 - kx0, 0.0)
                     else:
                         L.check(lib.dssvae_softmax_grad_inplace(L.ptr(dl), ldd, L.ptr(lse[m0:]), L.ptr(cnt[m0:]), rows,
@@ -830,7 +841,7 @@ class _LinearCEFn(Function):
                         if wg_done is not None and n_str > 1:
                             st.wait_event(wg_done)
                         if fuse:
-                            _gemm_dlogits(dl, ldd, rows, N, rowinfo[m0:], 1, xcat[m0:m0 + rows], xcat.stride(0), dWp,
+                            _gemm_dlogits(dl, ldd, rows, N, tab, 1, xcat[m0:m0 + rows], xcat.stride(0), dWp,
                                           Kw, Kw, 0.0 if m0 == 0 else 1.0)
                         else:
                             mm_tn(dl[:, :N], xcat[m0:m0 + rows], out=dWp, beta=0.0 if m0 == 0 else 1.0)

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 7 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache) */
+#define DSSVAE_ABI_VERSION 8 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -96,6 +96,16 @@ int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe,
                           const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
                           float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
                           float* logits, int64_t ldl, void* stream);
+/* The training path's form of the same call: the slab receives the row chunk NORMALISED per 128-column tile,
+ * slab[m,n] = exp(logit[m,n] - tile_max[n / 128][m]) (in (0, 1]), and tile_max [ceil(N / 128), ldt >= M] those maxima
+ * (the kernel computes these exponentials for its sums anyway).  dssvae_ce_rowscale then turns the table into one scale
+ * per (tile, row) in place, and dssvae_gemm_f32_dlogits applies it while staging: ONE multiply per slab element in the
+ * gradient GEMMs, where raw logits cost an fma and an exp each (every VALU instruction between fp32 MFMAs costs matrix
+ * time: DESIGN.md section 5).  slab 16-byte aligned, ldl % 4 == 0, N % 4 == 0, else DSSVAE_EINVAL.  Same reference ops. */
+int dssvae_linear_lse_fwd_norm(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
+                               const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
+                               float* part_max, float* part_sum, float* slab, int64_t ldl, float* tile_max,
+                               int64_t ldt, void* stream);
 
 /* X[m,n] <- coef[m] * exp(X[m,n] - lse[m]) in place on a logits slab [M, ldx] (ldx % 4 == 0);
  * colsum (may be NULL) [N] += column sums of the result (atomics: zero it first).  The softmax part
@@ -104,20 +114,22 @@ int dssvae_softmax_grad_inplace(float* X, int64_t ldx, const float* lse, const f
                                 float* colsum, void* stream);
 
 /* The two consumers of a logits slab with the softmax part of the gradient applied WHILE THE SLAB TILE IS STAGED
- * (no separate pass over the slab, nothing written back): with P[m,n] = coef[m] * exp(logits[m,n] - lse[m]),
+ * (no separate pass over the slab, nothing written back): with P[m,n] = coef[m] * exp(logit[m,n] - lse[m])
+ *                                                              = slab[m,n] * scale[n / 128][m]   (slab: dssvae_linear_lse_fwd_norm),
  *   trans_a = 0:  C[rows, N] (+)= P . B          B [cols, N] row-major   (dgrad: B = W_out panel)
  *   trans_a = 1:  C[cols, N] (+)= P^T . B        B [rows, N] row-major   (wgrad: B = [h | e | 1 0 0 0]: the column of
  *                                                ones makes the bias gradient come out as one more output column)
- * beta in {0, 1}.  rowinfo [rows] = (lse - ln coef) * log2(e) per slab row (+inf where coef = 0), written by
- * dssvae_ce_rowinfo.  The one-hot part of dlogits (dL[m, target[m]] -= w[m]) is applied to the PRODUCTS by
+ * beta in {0, 1}.  scale [ceil(cols / 128), ld_scale >= rows] = coef[m] * exp(tile_max - lse[m]) (0 where coef = 0), made
+ * in place from the tile_max table by dssvae_ce_rowscale(lse, coef, M, tiles, table, ld).  The one-hot part of dlogits (dL[m, target[m]] -= w[m]) is applied to the PRODUCTS by
  * dssvae_ce_onehot_fixup: dX[m,:] -= w W_panel[target[m],:] and dW[target[m],:] -= w Xc[m,:] (w = g[m], or 1 when g
  * is NULL; rows whose target is ignore_index are skipped; dX or dW may be NULL).
  * The slab and B must be 16-byte aligned with leading dimensions / cols / N multiples of 4, else DSSVAE_ETOOBIG
  * (the caller then uses dssvae_softmax_grad_inplace + dssvae_onehot_sub + dssvae_gemm_f32).
  * Replaces autograd of log_softmax + gather + the Linear's backward (decoder/rnn_decoder.py:70-73,94-102). */
-int dssvae_ce_rowinfo(const float* lse, const float* coef, int M, float* rowinfo, void* stream);
-int dssvae_gemm_f32_dlogits(const float* logits, int64_t ldl, int rows, int cols, const float* rowinfo, int trans_a,
-                            const float* B, int64_t ldb, float* C, int64_t ldc, int N, float beta, void* stream);
+int dssvae_ce_rowscale(const float* lse, const float* coef, int M, int tiles, float* table, int64_t ld, void* stream);
+int dssvae_gemm_f32_dlogits(const float* slab, int64_t ldl, int rows, int cols, const float* scale, int64_t ld_scale,
+                            int trans_a, const float* B, int64_t ldb, float* C, int64_t ldc, int N, float beta,
+                            void* stream);
 int dssvae_ce_onehot_fixup(const int64_t* target, int64_t ignore_index, const float* g, int rows,
                            const float* W_panel, int64_t ldw, int Kx, float* dX, int64_t lddx,
                            const float* Xc, int64_t ldxc, int Kw, float* dW, int64_t lddw, void* stream);
