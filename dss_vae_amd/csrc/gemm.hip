@@ -850,17 +850,15 @@ __global__ __launch_bounds__(NTHREADS) void gemm_group_sk_kernel(GroupArgs g) {
 // instead of one per accumulator row (32 per lane): the kernel fits 2 waves per SIMD (two
 // workgroups per CU), which is what hides the epilogue and the barrier skew behind the other
 // workgroup's MFMAs.  One 32-lane shuffle reduction per row at the very end.
-// STORE: 0 = statistics only; 1 = + the logits of the row chunk into the slab; 2 = + the slab NORMALISED per 128-column
-// tile: exp(x - max of the row within the tile), and that maximum into tile_max[tile][row] -- what the gradient GEMMs
-// (dssvae_gemm_f32_dlogits) multiply by one scale per (row, tile) while they stage it
+// STORE: 0 = statistics only; 1 = + the logits of the row chunk into the slab (the normalised slab of the training
+// path has a kernel of its own below)
 template <bool ARG, int VW, int STORE>
 __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
                                                                   int N, int K, int n_split, int tiles_per_split,
                                                                   int tiles_n, float* __restrict__ part_max,
                                                                   float* __restrict__ part_sum,
                                                                   int64_t* __restrict__ part_arg,
-                                                                  float* __restrict__ logits, int64_t ldl, int lvec,
-                                                                  float* __restrict__ tile_max, int64_t ldt) {
+                                                                  float* __restrict__ logits, int64_t ldl, int lvec) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int BM = 128, BN = 128, LDT = BN + 4;
     // 8 threads per row, each with every 8th 16-byte piece of it (4 pieces); 32 rows per pass, 4 passes: 4 running
@@ -917,34 +915,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
             float mt_ = m4[0];
 #pragma unroll
             for (int q = 1; q < QPT; ++q) mt_ = fmaxf(mt_, m4[q]);
-            if constexpr (STORE == 2) {
-                // the row's maximum within this tile: over the TPR lanes that hold the row's other pieces
-                float mr = mt_;
-#pragma unroll
-                for (int o = TPR / 2; o > 0; o >>= 1) mr = fmaxf(mr, __shfl_xor(mr, o, 64));
-                const float mn2 = fmaxf(mo, mr);
-                float add2 = 0.f;
-#pragma unroll
-                for (int q = 0; q < QPT; ++q) {
-                    v[q].x = __expf(v[q].x - mr); v[q].y = __expf(v[q].y - mr);
-                    v[q].z = __expf(v[q].z - mr); v[q].w = __expf(v[q].w - mr);
-                    add2 += (v[q].x + v[q].y) + (v[q].z + v[q].w);
-                }
-                rs[i] = rs[i] * __expf(mo - mn2) + add2 * __expf(mr - mn2);
-                rm[i] = mn2;   // (the same in all lanes of the row: every tile's maximum is shared)
-                const int m = m0 + row;
-                if (m < M) {
-                    if ((threadIdx.x % TPR) == 0) tile_max[(int64_t)tn * ldt + m] = mr;
-#pragma unroll
-                    for (int q = 0; q < QPT; ++q) {
-                        const int n = n0 + col + 4 * TPR * q;
-                        if (n < N)   // (ldl and N are multiples of 4 in this mode: the host checks)
-                            __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v[q]),
-                                                        reinterpret_cast<f32x4*>(logits + (int64_t)m * ldl + n));
-                    }
-                }
-                continue;
-            }
             const float mn = fmaxf(mo, mt_);
             float add = 0.f;
 #pragma unroll
@@ -1014,6 +984,115 @@ __global__ __launch_bounds__(NTHREADS, 2) void linear_lse_kernel(OpA a, OpB b, c
             part_sum[(int64_t)gm * n_split + split] = s;
             if (ARG) part_arg[(int64_t)gm * n_split + split] = ai;
         }
+    }
+}
+
+// The training path's form: the slab NORMALISED per 128-column tile -- slab[m, n] = exp(x - max of row m within the
+// tile), exponentials the statistics need anyway -- with (max, sum) of every (tile, row) in two [tiles_n][ldt] tables:
+// the gradient GEMMs multiply a staged granule by ONE scale per (row, tile) (dssvae_ce_rowscale makes it from the maxima).
+// No state crosses a tile, so the tiles are dealt as ONE list -- column tile major, row block minor -- in equal shares to
+// a grid of exactly two workgroups per CU: 14 570 tiles over 512 workgroups are 28 or 29 each (column splits per row
+// block gave 496 workgroups 29 or 30); a workgroup keeps its W tile through ~28 row blocks, neighbours on its XCD (a
+// contiguous share of the list per XCD) the same or the next one.
+template <int VW>
+__global__ __launch_bounds__(NTHREADS, 2) void linear_lse_norm_kernel(OpA a, OpB b, const float* __restrict__ bias, int M,
+                                                                       int N, int K, int tiles_m, int tiles_n,
+                                                                       float* __restrict__ slab, int64_t ldl,
+                                                                       float* __restrict__ tile_max,
+                                                                       float* __restrict__ tile_sum, int64_t ldt) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int BM = 128, BN = 128, LDT = BN + 4;
+    constexpr int TPR = 8, QPT = BN / 4 / TPR, RPP = NTHREADS / TPR, NR = BM / RPP;
+    static_assert(BM * LDT <= lds_floats<false, false, 2, 2>(), "tile image must fit in the operand buffers");
+    const int T = tiles_m * tiles_n, G = (int)gridDim.x, w = xcd_remap(blockIdx.x, G);
+    const int q = T / G, rem = T - q * G;
+    const int f0 = w * q + min(w, rem), f1 = f0 + q + (w < rem ? 1 : 0);
+    const int nk = (K + BK - 1) / BK;
+    const int col = 4 * (threadIdx.x % TPR), rbase = threadIdx.x / TPR;
+    for (int f = f0; f < f1; ++f) {
+        const int tn = f / tiles_m, mb = f - tn * tiles_m;
+        const int m0 = mb * BM, n0 = tn * BN;
+        f32x16 acc[2][2];
+        tile_mainloop<false, false, VW, 2, 2>(a, b, M, N, K, m0, n0, 0, nk, lds, acc);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int c = n0 + acc_col<2>(nt);
+            const bool ok = c < N;
+            const float bv = (bias && ok) ? bias[c] : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    lds[acc_row<2>(mt, r) * LDT + acc_col<2>(nt)] = ok ? acc[mt][nt][r] + bv : NEG_BIG;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            const int row = rbase + RPP * i, m = m0 + row;
+            float4 v[QPT];
+#pragma unroll
+            for (int qq = 0; qq < QPT; ++qq) v[qq] = *reinterpret_cast<const float4*>(lds + row * LDT + col + 4 * TPR * qq);
+            float mr = fmaxf(fmaxf(v[0].x, v[0].y), fmaxf(v[0].z, v[0].w));
+#pragma unroll
+            for (int qq = 1; qq < QPT; ++qq) mr = fmaxf(mr, fmaxf(fmaxf(v[qq].x, v[qq].y), fmaxf(v[qq].z, v[qq].w)));
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) mr = fmaxf(mr, __shfl_xor(mr, o, 64));   // the row's 8 lanes
+            float add = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < QPT; ++qq) {
+                v[qq].x = __expf(v[qq].x - mr); v[qq].y = __expf(v[qq].y - mr);
+                v[qq].z = __expf(v[qq].z - mr); v[qq].w = __expf(v[qq].w - mr);
+                add += (v[qq].x + v[qq].y) + (v[qq].z + v[qq].w);
+            }
+#pragma unroll
+            for (int o = TPR / 2; o > 0; o >>= 1) add += __shfl_xor(add, o, 64);
+            if (m < M) {
+                if ((threadIdx.x % TPR) == 0) {
+                    tile_max[(int64_t)tn * ldt + m] = mr;
+                    tile_sum[(int64_t)tn * ldt + m] = add;
+                }
+#pragma unroll
+                for (int qq = 0; qq < QPT; ++qq) {
+                    const int n = n0 + col + 4 * TPR * qq;
+                    if (n < N)   // streaming store (see linear_lse_kernel); ldl and N are multiples of 4 (host check)
+                        __builtin_nontemporal_store(__builtin_bit_cast(f32x4, v[qq]),
+                                                    reinterpret_cast<f32x4*>(slab + (int64_t)m * ldl + n));
+                }
+            }
+        }
+        __syncthreads();  // the image aliases the operand buffers of the next tile
+    }
+}
+
+// lse[m] from the per-tile (max, sum) tables of linear_lse_norm_kernel: a workgroup takes 32 rows, 8 threads per row
+// walk every 8th tile with a running (max, sum) and meet in LDS (a thread per row looping over all 235 tiles twice
+// was 100 us of dependent latency per call)
+__global__ __launch_bounds__(256) void lse_combine_tiles_kernel(const float* __restrict__ tmax,
+                                                                const float* __restrict__ tsum, int M, int tiles,
+                                                                int64_t ld, float* __restrict__ lse) {
+    __shared__ float sm[8][32], ss[8][32];
+    const int r = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int m = blockIdx.x * 32 + r;
+    float mx = NEG_BIG, acc = 0.f;
+    if (m < M) {
+        for (int t = part; t < tiles; t += 8) {
+            const float x = tmax[(int64_t)t * ld + m], ts = tsum[(int64_t)t * ld + m];
+            const float mn = fmaxf(mx, x);
+            acc = acc * __expf(mx - mn) + ts * __expf(x - mn);
+            mx = mn;
+        }
+    }
+    sm[part][r] = mx;
+    ss[part][r] = acc;
+    __syncthreads();
+    if (part == 0 && m < M) {
+        float m2 = sm[0][r];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) m2 = fmaxf(m2, sm[p][r]);
+        float a2 = 0.f;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) a2 += ss[p][r] * __expf(sm[p][r] - m2);
+        lse[m] = m2 + __logf(a2);
     }
 }
 
@@ -1543,12 +1622,9 @@ extern "C" int dssvae_gemm_f32_grouped(const dssvae_gemm_problem* pr, int n, int
 
 static int lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke, const float* W,
                    int64_t ldw, const float* bias, int M, int N, int n_split, float* part_max, float* part_sum,
-                   int64_t* part_arg, int want_argmax, float* logits, int64_t ldl, float* tile_max, int64_t ldt,
-                   void* stream) {
+                   int64_t* part_arg, int want_argmax, float* logits, int64_t ldl, void* stream) {
     if (!Xh || !W || !part_max || !part_sum || M <= 0 || N <= 0 || Kh <= 0 || Ke < 0 || n_split <= 0)
         return DSSVAE_EINVAL;
-    // the normalised slab leaves as 16-byte pieces only
-    if (tile_max && (!logits || ldt < M || !aligned16(logits) || (ldl % 4) != 0 || (N % 4) != 0)) return DSSVAE_EINVAL;
     if (Ke > 0 && !Xe) return DSSVAE_EINVAL;
     if (want_argmax && !part_arg) return DSSVAE_EINVAL;
     if (logits && (ldl < N || want_argmax)) return DSSVAE_EINVAL;
@@ -1571,14 +1647,13 @@ static int lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_
         allow_lds(linear_lse_kernel<ARG, VW, ST>, lds_bytes);                                                     \
         hipLaunchKernelGGL((linear_lse_kernel<ARG, VW, ST>), dim3(tiles_m * n_split), dim3(NTHREADS), lds_bytes,  \
                            s, a, b, bias, M, N, Kh + Ke, n_split, tps, tiles_n, part_max, part_sum, part_arg,     \
-                           logits, ldl, lvec, tile_max, ldt);                                                     \
+                           logits, ldl, lvec);                                                                    \
     } while (0)
 #define GO(ARG, ST)                                                                                               \
     do {                                                                                                          \
         if (vw == 4) GO1(ARG, 4, ST); else if (vw == 2) GO1(ARG, 2, ST); else GO1(ARG, 1, ST);                    \
     } while (0)
-    if (logits && tile_max) GO(false, 2);
-    else if (logits) GO(false, 1);
+    if (logits) GO(false, 1);
     else if (want_argmax) GO(true, 0);
     else GO(false, 0);
 #undef GO
@@ -1592,16 +1667,50 @@ extern "C" int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const
                                      float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
                                      float* logits, int64_t ldl, void* stream) {
     return lse_fwd(Xh, ldh, Kh, Xe, lde, Ke, W, ldw, bias, M, N, n_split, part_max, part_sum, part_arg, want_argmax,
-                   logits, ldl, nullptr, 0, stream);
+                   logits, ldl, stream);
 }
 
 extern "C" int dssvae_linear_lse_fwd_norm(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
-                                          const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
-                                          float* part_max, float* part_sum, float* slab, int64_t ldl,
-                                          float* tile_max, int64_t ldt, void* stream) {
-    if (!slab || !tile_max) return DSSVAE_EINVAL;
-    return lse_fwd(Xh, ldh, Kh, Xe, lde, Ke, W, ldw, bias, M, N, n_split, part_max, part_sum, nullptr, 0, slab, ldl,
-                   tile_max, ldt, stream);
+                                          const float* W, int64_t ldw, const float* bias, int M, int N, float* slab,
+                                          int64_t ldl, float* tile_max, float* tile_sum, int64_t ldt, void* stream) {
+    if (!Xh || !W || !slab || !tile_max || !tile_sum || M <= 0 || N <= 0 || Kh <= 0 || Ke < 0 || (Ke > 0 && !Xe))
+        return DSSVAE_EINVAL;
+    // the normalised slab leaves as 16-byte pieces only
+    if (ldl < N || ldt < M || !aligned16(slab) || (ldl % 4) != 0 || (N % 4) != 0) return DSSVAE_EINVAL;
+    bool vec;
+    OpA a = make_panels(Xh, ldh, Kh, Xe, lde, Ke, &vec);
+    OpB b;
+    b.p = W; b.ld = ldw;
+    vec = vec && vec_ok(W, ldw);
+    const int vw = !vec ? 1 : ((Ke == 0 && fast_span_ok(ldh, false, M) && fast_span_ok(ldw, false, N)) ? 4 : 2);
+    const int tiles_m = (M + 127) / 128, tiles_n = (N + 127) / 128;
+    const int64_t T = (int64_t)tiles_m * tiles_n;
+    if (T >= ((int64_t)1 << 30)) return DSSVAE_ETOOBIG;
+    const int slots = tune_env("DSSVAE_GEMM_SLOTS", 2) * n_cus_cached();
+    // fewer than two rounds of tiles: one tile per workgroup, the dispatcher backfills (546 tiles as 512 workgroups of
+    // one or two tiles took 0.333 ms, as 546 workgroups 0.257); else equal shares of the list to one round
+    const int grid = (int)(T < 2 * (int64_t)slots ? T : slots);
+    hipStream_t s = (hipStream_t)stream;
+    constexpr int lds_bytes = lds_floats<false, false, 2, 2>() * 4;
+#define GO1(VW)                                                                                                   \
+    do {                                                                                                          \
+        allow_lds(linear_lse_norm_kernel<VW>, lds_bytes);                                                         \
+        hipLaunchKernelGGL((linear_lse_norm_kernel<VW>), dim3(grid), dim3(NTHREADS), lds_bytes, s, a, b, bias, M, \
+                           N, Kh + Ke, tiles_m, tiles_n, slab, ldl, tile_max, tile_sum, ldt);                      \
+    } while (0)
+    if (vw == 4) GO1(4); else if (vw == 2) GO1(2); else GO1(1);
+#undef GO1
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_lse_combine_tiles(const float* tile_max, const float* tile_sum, int M, int tiles, int64_t ldt,
+                                        float* lse, void* stream) {
+    if (!tile_max || !tile_sum || !lse || M <= 0 || tiles <= 0 || ldt < M) return DSSVAE_EINVAL;
+    hipLaunchKernelGGL(lse_combine_tiles_kernel, dim3((M + 31) / 32), dim3(256), 0, (hipStream_t)stream, tile_max,
+                       tile_sum, M, tiles, ldt, lse);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
 }
 
 extern "C" int dssvae_lse_combine(const float* part_max, const float* part_sum, const int64_t* part_arg, int M,

@@ -73,7 +73,8 @@ _SIGNATURES = {
     "dssvae_linear_lse_fwd": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_softmax_grad_inplace": ([_P, _L, _P, _P, _I, _I, _P, _P], _I),
     "dssvae_ce_rowscale": ([_P, _P, _I, _I, _P, _L, _P], _I),
-    "dssvae_linear_lse_fwd_norm": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _I, _P, _P, _P, _L, _P, _L, _P], _I),
+    "dssvae_linear_lse_fwd_norm": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P, _P, _L, _P], _I),
+    "dssvae_lse_combine_tiles": ([_P, _P, _I, _I, _L, _P, _P], _I),
     "dssvae_ce_onehot_fixup": ([_P, _L, _P, _I, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P], _I),
     "dssvae_gemm_f32_dlogits": ([_P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _L, _I, _F, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),

@@ -649,7 +649,24 @@ def _one_panel(xh, xe):
 
 def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None, lse_out=None, tile_max=None):
     """tile_max ([ceil(N / 128), >= M] floats): `logits` receives the slab normalised per 128-column tile and the
-    table the tiles' row maxima (dssvae_linear_lse_fwd_norm) instead of raw logits"""
+    table the tiles' row maxima (dssvae_linear_lse_fwd_norm: tiles dealt evenly, no column splits) instead of raw logits"""
+    if tile_max is not None:
+        assert not want_arg
+        if xe is not None and Ke > 0 and (Kh + Ke) % 4 == 0:
+            xh, xe = _one_panel(xh[:M], xe[:M]), None
+            ldh, Kh, lde, Ke = xh.stride(0), Kh + Ke, 0, 0
+        lib = L.load()
+        tsum = torch.empty_like(tile_max)
+        tiles = tile_max.size(0)
+        with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * tiles),
+                   detail="M=%d N=%d K=%d+%d tiles normalised store" % (M, N, Kh, Ke)):
+            L.check(lib.dssvae_linear_lse_fwd_norm(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N,
+                                                   L.ptr(logits), logits.stride(0), L.ptr(tile_max), L.ptr(tsum),
+                                                   tile_max.stride(0), L.stream()), "dssvae_linear_lse_fwd_norm")
+        lse = torch.empty(M, device=xh.device, dtype=torch.float32) if lse_out is None else lse_out
+        L.check(lib.dssvae_lse_combine_tiles(L.ptr(tile_max), L.ptr(tsum), M, tiles, tile_max.stride(0), L.ptr(lse),
+                                             L.stream()), "dssvae_lse_combine_tiles")
+        return lse, None
     if xe is not None and Ke > 0 and (Kh + Ke) % 4 == 0:
         xh, xe = _one_panel(xh[:M], xe[:M]), None
         ldh, Kh, lde, Ke = xh.stride(0), Kh + Ke, 0, 0
@@ -661,16 +678,10 @@ def _lse(xh, ldh, Kh, xe, lde, Ke, W, ldw, b, M, N, want_arg=False, logits=None,
     lib = L.load()
     with _Span("linear_lse_kernel", 2.0 * M * N * (Kh + Ke), 4.0 * (M * (Kh + Ke) + N * (Kh + Ke) + 2 * M * S),
                detail="M=%d N=%d K=%d+%d S=%d%s" % (M, N, Kh, Ke, S, " store" if logits is not None else "")):
-        if tile_max is not None:
-            L.check(lib.dssvae_linear_lse_fwd_norm(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N,
-                                                   S, L.ptr(pm), L.ptr(ps), L.ptr(logits), logits.stride(0),
-                                                   L.ptr(tile_max), tile_max.stride(0), L.stream()),
-                    "dssvae_linear_lse_fwd_norm")
-        else:
-            L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
-                                              L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
-                                              0 if logits is None else logits.stride(0), L.stream()),
-                    "dssvae_linear_lse_fwd")
+        L.check(lib.dssvae_linear_lse_fwd(L.ptr(xh), ldh, Kh, L.ptr(xe), lde, Ke, L.ptr(W), ldw, L.ptr(b), M, N, S,
+                                          L.ptr(pm), L.ptr(ps), L.ptr(pa), int(want_arg), L.ptr(logits),
+                                          0 if logits is None else logits.stride(0), L.stream()),
+                "dssvae_linear_lse_fwd")
     lse = torch.empty(M, device=dev, dtype=torch.float32) if lse_out is None else lse_out
     arg = torch.empty(M, device=dev, dtype=torch.int64) if want_arg else None
     L.check(lib.dssvae_lse_combine(L.ptr(pm), L.ptr(ps), L.ptr(pa), M, S, L.ptr(lse), L.ptr(arg), L.stream()),

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 8 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table */
+#define DSSVAE_ABI_VERSION 8 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -96,16 +96,19 @@ int dssvae_linear_lse_fwd(const float* Xh, int64_t ldh, int Kh, const float* Xe,
                           const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
                           float* part_max, float* part_sum, int64_t* part_arg, int want_argmax,
                           float* logits, int64_t ldl, void* stream);
-/* The training path's form of the same call: the slab receives the row chunk NORMALISED per 128-column tile,
- * slab[m,n] = exp(logit[m,n] - tile_max[n / 128][m]) (in (0, 1]), and tile_max [ceil(N / 128), ldt >= M] those maxima
- * (the kernel computes these exponentials for its sums anyway).  dssvae_ce_rowscale then turns the table into one scale
- * per (tile, row) in place, and dssvae_gemm_f32_dlogits applies it while staging: ONE multiply per slab element in the
- * gradient GEMMs, where raw logits cost an fma and an exp each (every VALU instruction between fp32 MFMAs costs matrix
- * time: DESIGN.md section 5).  slab 16-byte aligned, ldl % 4 == 0, N % 4 == 0, else DSSVAE_EINVAL.  Same reference ops. */
+/* The training path's form: the slab receives the row chunk NORMALISED per 128-column tile,
+ * slab[m,n] = exp(logit[m,n] - tile_max[n / 128][m]) (in (0, 1]), and tile_max / tile_sum [ceil(N / 128), ldt >= M] the
+ * maximum and the sum of those exponentials of every (tile, row) (the exponentials the statistics need anyway).  No state
+ * crosses a tile, so the tiles are dealt as one list in equal shares to two workgroups per CU (no n_split).
+ * dssvae_lse_combine_tiles gives lse[m]; dssvae_ce_rowscale then turns tile_max into one scale per (tile, row) in place,
+ * and dssvae_gemm_f32_dlogits applies it while staging: ONE multiply per slab element in the gradient GEMMs, where raw
+ * logits cost an fma and an exp each (every VALU instruction between fp32 MFMAs costs matrix time: DESIGN.md section 5).
+ * slab 16-byte aligned, ldl % 4 == 0, N % 4 == 0, else DSSVAE_EINVAL.  Same reference ops as dssvae_linear_lse_fwd. */
 int dssvae_linear_lse_fwd_norm(const float* Xh, int64_t ldh, int Kh, const float* Xe, int64_t lde, int Ke,
-                               const float* W, int64_t ldw, const float* bias, int M, int N, int n_split,
-                               float* part_max, float* part_sum, float* slab, int64_t ldl, float* tile_max,
-                               int64_t ldt, void* stream);
+                               const float* W, int64_t ldw, const float* bias, int M, int N, float* slab,
+                               int64_t ldl, float* tile_max, float* tile_sum, int64_t ldt, void* stream);
+int dssvae_lse_combine_tiles(const float* tile_max, const float* tile_sum, int M, int tiles, int64_t ldt, float* lse,
+                             void* stream);
 
 /* X[m,n] <- coef[m] * exp(X[m,n] - lse[m]) in place on a logits slab [M, ldx] (ldx % 4 == 0);
  * colsum (may be NULL) [N] += column sums of the result (atomics: zero it first).  The softmax part
