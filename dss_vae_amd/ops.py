@@ -852,6 +852,9 @@ class _LinearCEFn(Function):
                         if wg_done is not None and n_str > 1:
                             st.wait_event(wg_done)
                         if fuse:
+                            # (the last 8 output columns -- 904 = 7 x 128 + 8 -- as a launch of their own on a side
+                            # stream, to fill the wide launch's last round: measured 0.25 ms SLOWER per step, the two
+                            # launches take CUs from each other from the start)
                             _gemm_dlogits(dl, ldd, rows, N, tab, 1, xcat[m0:m0 + rows], xcat.stride(0), dWp,
                                           Kw, Kw, 0.0 if m0 == 0 else 1.0)
                         else:
