@@ -66,24 +66,27 @@ struct Ws {
     int64_t* parg;   // [B,S]
     int64_t* tok;    // [B]
     float* h;        // [2][L][B,H]  (ping-pong: the fused cell step writes h' beside h)
+    float* c;        // [L][B,H]     (LSTM: the cell state, updated in place)
     size_t bytes;
 };
 
 inline size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-Ws carve(void* base, int B, int E, int H, int L, int S) {
+Ws carve(void* base, int B, int E, int H, int L, int S, bool lstm = false) {
+    const int G = lstm ? 4 : 3;
     Ws w;
     char* p = static_cast<char*>(base);
     size_t off = 0;
     auto take = [&](size_t n) { size_t o = off; off += up256(n); return p ? p + o : nullptr; };
     w.x = reinterpret_cast<float*>(take((size_t)B * E * 4));
-    w.gi = reinterpret_cast<float*>(take((size_t)B * 3 * H * 4));
-    w.gh = reinterpret_cast<float*>(take((size_t)B * 3 * H * 4));
+    w.gi = reinterpret_cast<float*>(take((size_t)B * G * H * 4));
+    w.gh = reinterpret_cast<float*>(take((size_t)B * G * H * 4));
     w.pmax = reinterpret_cast<float*>(take((size_t)B * S * 4));
     w.psum = reinterpret_cast<float*>(take((size_t)B * S * 4));
     w.parg = reinterpret_cast<int64_t*>(take((size_t)B * S * 8));
     w.tok = reinterpret_cast<int64_t*>(take((size_t)B * 8));
     w.h = reinterpret_cast<float*>(take((size_t)2 * L * B * H * 4));
+    w.c = lstm ? reinterpret_cast<float*>(take((size_t)L * B * H * 4)) : nullptr;
     w.bytes = off;
     return w;
 }
@@ -132,17 +135,17 @@ int small_linear(const float* X, int K, const float* W, const float* b, int B, i
     if (rc == DSSVAE_ETOOBIG) rc = dssvae_gemm_f32(X, K, 0, nullptr, W, K, 0, C, N, b, B, N, K, 1.f, 0.f, stream);
     return rc;
 }
-}  // namespace
 
-extern "C" int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V) {
-    if (B <= 0 || E <= 0 || H <= 0 || V <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
-        return DSSVAE_EINVAL;
-    return (int64_t)carve(nullptr, B, E, H, n_layers, part_cols(n_split, V)).bytes;
+int check_shape(int B, int E, int H, int n_layers, int n_split, int V) {
+    return (B <= 0 || E <= 0 || H <= 0 || V <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
+               ? DSSVAE_EINVAL : DSSVAE_OK;
 }
 
-extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* h0, int B, int max_len,
-                                    int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
-                                    int64_t workspace_bytes, void* stream) {
+// the loop for either cell: c0 == NULL -> GRU, else LSTM (weights [4H, .], the state is the pair (h, c))
+int greedy_loop(const dssvae_decode_params* p, const float* h0, const float* c0, int B, int max_len, int64_t sos_id,
+                int n_split, int64_t* tokens, float* h_final, float* c_final, void* workspace, int64_t workspace_bytes,
+                void* stream) {
+    const bool lstm = c0 != nullptr;
     if (!p || !h0 || !tokens || !workspace || B <= 0 || max_len <= 0 || n_split <= 0) return DSSVAE_EINVAL;
     const int E = p->E, H = p->H, L = p->n_layers, V = p->V;
     if (E <= 0 || H <= 0 || V <= 0 || L <= 0 || L > DSSVAE_DECODE_MAX_LAYERS || !p->embedding || !p->w_out ||
@@ -151,11 +154,15 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
     for (int l = 0; l < L; ++l)
         if (!p->w_ih[l] || !p->w_hh[l] || !p->b_ih[l] || !p->b_hh[l]) return DSSVAE_EINVAL;
     if (!aligned16(workspace)) return DSSVAE_EINVAL;
-    const Ws w = carve(workspace, B, E, H, L, part_cols(n_split, V));
+    const Ws w = carve(workspace, B, E, H, L, part_cols(n_split, V), lstm);
     if ((int64_t)w.bytes > workspace_bytes) return DSSVAE_EINVAL;
     hipStream_t s = (hipStream_t)stream;
     hipError_t e = hipMemcpyAsync(w.h, h0, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
     if (e != hipSuccess) return (int)e;
+    if (lstm) {
+        e = hipMemcpyAsync(w.c, c0, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(fill_i64_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.tok, sos_id, B);
     DSSVAE_CHECK_LAUNCH();
     int rc;
@@ -178,11 +185,16 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
         for (int l = 0; l < L; ++l) {
             float* hl = w.h + ((size_t)cur[l] * L + l) * B * H;
             float* hn = w.h + ((size_t)(cur[l] ^ 1) * L + l) * B * H;
+            float* cl = lstm ? w.c + (size_t)l * B * H : nullptr;
             rc = DSSVAE_ETOOBIG;
             if (l == 0 && pending) {
-                rc = dssvae_skinny_gru_step_pick(w.pmax, w.parg, S_prev, tokens + (size_t)(t - 1) * B, p->embedding,
-                                                 p->ld_embedding, E, w.x, E, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l],
-                                                 H, p->b_ih[l], p->b_hh[l], B, hn, H, stream);
+                rc = lstm ? dssvae_skinny_lstm_step_pick(w.pmax, w.parg, S_prev, tokens + (size_t)(t - 1) * B,
+                                                         p->embedding, p->ld_embedding, E, w.x, E, hl, H, H, cl, cl, H,
+                                                         p->w_ih[l], in_dim, p->w_hh[l], H, p->b_ih[l], p->b_hh[l], B,
+                                                         hn, H, stream)
+                          : dssvae_skinny_gru_step_pick(w.pmax, w.parg, S_prev, tokens + (size_t)(t - 1) * B,
+                                                        p->embedding, p->ld_embedding, E, w.x, E, hl, H, H, p->w_ih[l],
+                                                        in_dim, p->w_hh[l], H, p->b_ih[l], p->b_hh[l], B, hn, H, stream);
                 if (rc != DSSVAE_OK && rc != DSSVAE_ETOOBIG) return rc;
                 if (rc == DSSVAE_ETOOBIG) {
                     pick_alone(t - 1);
@@ -191,15 +203,25 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
                 pending = false;
             }
             if (rc == DSSVAE_ETOOBIG)
-                rc = dssvae_skinny_gru_step(in, in_dim, in_dim, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l], H,
-                                            p->b_ih[l], p->b_hh[l], B, hn, H, stream);
+                rc = lstm ? dssvae_skinny_lstm_step(in, in_dim, in_dim, hl, H, H, cl, cl, H, p->w_ih[l], in_dim,
+                                                    p->w_hh[l], H, p->b_ih[l], p->b_hh[l], B, hn, H, stream)
+                          : dssvae_skinny_gru_step(in, in_dim, in_dim, hl, H, H, p->w_ih[l], in_dim, p->w_hh[l], H,
+                                                   p->b_ih[l], p->b_hh[l], B, hn, H, stream);
             if (rc == DSSVAE_OK) {
                 cur[l] ^= 1;
                 hl = hn;
             } else if (rc == DSSVAE_ETOOBIG) {  // outside the fused kernel's range: two products + the cell
-                TRY(small_linear(in, in_dim, p->w_ih[l], p->b_ih[l], B, 3 * H, w.gi, stream));
-                TRY(small_linear(hl, H, p->w_hh[l], p->b_hh[l], B, 3 * H, w.gh, stream));
-                TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
+                const int G = lstm ? 4 : 3;
+                TRY(small_linear(in, in_dim, p->w_ih[l], p->b_ih[l], B, G * H, w.gi, stream));
+                if (lstm) {
+                    // (dssvae_lstm_step_fwd adds its bias argument to gh itself: the product goes in without one)
+                    TRY(small_linear(hl, H, p->w_hh[l], nullptr, B, G * H, w.gh, stream));
+                    TRY(dssvae_lstm_step_fwd(w.gi, (int64_t)G * H, w.gh, p->b_hh[l], hl, cl, nullptr, 0, B, H, hl, cl,
+                                             nullptr, 0, nullptr, 0, stream));  // element-wise: in place is safe
+                } else {
+                    TRY(small_linear(hl, H, p->w_hh[l], p->b_hh[l], B, G * H, w.gh, stream));
+                    TRY(dssvae_gru_cell(w.gi, w.gh, hl, B, H, hl, stream));  // element-wise: in place is safe
+                }
             } else {
                 return rc;
             }
@@ -232,7 +254,39 @@ extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* 
             if (e != hipSuccess) return (int)e;
         }
     }
+    if (lstm && c_final) {
+        e = hipMemcpyAsync(c_final, w.c, (size_t)L * B * H * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) return (int)e;
+    }
     return DSSVAE_OK;
+}
+}  // namespace
+
+extern "C" int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V) {
+    if (B <= 0 || E <= 0 || H <= 0 || V <= 0 || n_layers <= 0 || n_layers > DSSVAE_DECODE_MAX_LAYERS || n_split <= 0)
+        return DSSVAE_EINVAL;
+    return (int64_t)carve(nullptr, B, E, H, n_layers, part_cols(n_split, V)).bytes;
+}
+
+extern "C" int dssvae_greedy_decode(const dssvae_decode_params* p, const float* h0, int B, int max_len,
+                                    int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
+                                    int64_t workspace_bytes, void* stream) {
+    return greedy_loop(p, h0, nullptr, B, max_len, sos_id, n_split, tokens, h_final, nullptr, workspace,
+                       workspace_bytes, stream);
+}
+
+// The loop for nn.LSTM decoders (rnn_cell = "lstm": decoder/rnn_decoder.py:43,65,160-168): the state is (h, c)
+extern "C" int64_t dssvae_greedy_decode_lstm_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V) {
+    if (check_shape(B, E, H, n_layers, n_split, V) != DSSVAE_OK) return DSSVAE_EINVAL;
+    return (int64_t)carve(nullptr, B, E, H, n_layers, part_cols(n_split, V), true).bytes;
+}
+
+extern "C" int dssvae_greedy_decode_lstm(const dssvae_decode_params* p, const float* h0, const float* c0, int B,
+                                         int max_len, int64_t sos_id, int n_split, int64_t* tokens, float* h_final,
+                                         float* c_final, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!c0) return DSSVAE_EINVAL;
+    return greedy_loop(p, h0, c0, B, max_len, sos_id, n_split, tokens, h_final, c_final, workspace, workspace_bytes,
+                       stream);
 }
 
 // The same loop with its workspace in the library's own per-GPU `scratch` array: no hipMalloc / hipFree, no

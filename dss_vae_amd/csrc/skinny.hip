@@ -452,12 +452,23 @@ struct SkgPick {
     int64_t ldxo;
 };
 
-template <int MT, bool PICK>
+// LSTM: the same launch for nn.LSTM's cell (gate order i, f, g, o; decoder/rnn_decoder.py:43,65 with rnn_cell = "lstm").
+// Its pre-activations are plain sums gi + gh, so [x | h] is ONE k range per gate: the twelve waves are 4 gates x 3
+// thirds of the concatenated range (a wave's third may straddle the panels: the weight row is picked per group), the
+// cell adds the three partials, reads c (Cp) and writes c' (Cn; Cn == Cp is fine: an element is read and written by
+// one lane) beside h'.
+struct SkgCell {
+    const float* cp;   // [M][H] c of the previous step (LSTM)
+    float* cn;         // [M][H] c' (may alias cp)
+    int64_t ldc;
+};
+
+template <int MT, bool PICK, bool LSTM>
 __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const float* __restrict__ X, int64_t ldx, int In, const float* __restrict__ Hp, int64_t ldh, int H,
     const float* __restrict__ Wih, int64_t ldi, const float* __restrict__ Whh, int64_t ldhh,
     const float* __restrict__ bih, const float* __restrict__ bhh, int M, int Kp, float* __restrict__ Hn, int64_t ldo,
-    int n_ub, int m_chunks, SkgPick pk) {
+    int n_ub, int m_chunks, SkgPick pk, SkgCell cell) {
     extern __shared__ __attribute__((aligned(16))) float Xs[];  // [16 MT][Kp] = [x .. 0 | h .. 0], each padded to 16; + 4 spare
     __shared__ __attribute__((aligned(16))) float part[SKG_WAVES][MT][64][4];
     __shared__ int tok_s[16 * MT];
@@ -473,20 +484,30 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     const int u0 = bx * 16;
     // wave -> (weight block, k half): waves land on SIMD wave % 4, and the x blocks are longer than the h blocks when
     // In > H; swapping the pairs of the second quad gives every SIMD both kinds instead of three of one
-    const int slot = wave ^ ((wave >> 2) & 1);
+    // (LSTM: wave -> (gate = wave % 4, third = wave / 4): every SIMD holds one gate's three thirds)
+    const int slot = LSTM ? wave : wave ^ ((wave >> 2) & 1);
     const int prod = slot % 6, khalf = slot / 6;
-    const int gate = prod >> 1, panel = prod & 1;
+    const int gate = LSTM ? (wave & 3) : (prod >> 1), panel = LSTM ? 0 : (prod & 1);
     const int Kw = panel ? H : In, xoff = panel ? Inp : 0;
     const float* wrow = (panel ? Whh : Wih) + (int64_t)(gate * H + min(u0 + r16, H - 1)) * (panel ? ldhh : ldi) + 4 * kq;
-    const int nG = (Kw + 15) >> 4, gper = (nG + 1) >> 1;
-    const int g_lo = khalf * gper, g_hi = min(nG, g_lo + gper);
+    const float* wrow_h = Whh + (int64_t)(gate * H + min(u0 + r16, H - 1)) * ldhh + 4 * kq;   // (LSTM: the h panel's row)
+    const int nGx = Inp >> 4;
+    const int nG = LSTM ? nGx + ((H + 15) >> 4) : (Kw + 15) >> 4, gper = LSTM ? (nG + 2) / 3 : (nG + 1) >> 1;
+    const int g_lo = (LSTM ? wave >> 2 : khalf) * gper, g_hi = min(nG, g_lo + gper);
     // the first weight chunk is on its way while the workgroup builds the [x | h] image
     // Unconditional loads at clamped addresses (a group past the wave's range is never multiplied; a lane past Kw
     // meets the image's zero padding): guarded loads came out as a branch each, with a full wait after the second
     // -- a memory round trip more in a kernel that is three of them long.
     auto loadw = [&](int g) -> f32x4 {
-        const int k = 16 * min(g, max(g_hi, g_lo + 1) - 1);   // (wrow already carries the lane's 4 * kq)
-        return *reinterpret_cast<const f32x4*>(wrow + max(min(k, Kw - 4 - 4 * kq), -4 * kq));
+        const int gc = min(g, max(g_hi, g_lo + 1) - 1);
+        if constexpr (LSTM) {
+            const bool hp = gc >= nGx;   // which panel the group lies in (the image is [x .. 0 | h .. 0]: same index)
+            const int k = 16 * (hp ? gc - nGx : gc);
+            return *reinterpret_cast<const f32x4*>((hp ? wrow_h : wrow) + max(min(k, (hp ? H : In) - 4 - 4 * kq), -4 * kq));
+        } else {
+            const int k = 16 * gc;   // (wrow already carries the lane's 4 * kq)
+            return *reinterpret_cast<const f32x4*>(wrow + max(min(k, Kw - 4 - 4 * kq), -4 * kq));
+        }
     };
     // The [x | h] image: a thread owns one row and every TPR-th 16-byte column of it (no division by a run-time
     // value, no branch around a load: clamped addresses, masked when stored).  The image's loads are issued BEFORE
@@ -623,37 +644,65 @@ __global__ __launch_bounds__(SKG_THREADS) void skinny_gru_kernel(
     // the cell's biases for the waves that apply it: all 24 loads back to back at clamped indices BEFORE the barrier
     // (one memory round trip under the wait for the other waves; guarded loads inside the per-unit branches below
     // were a round trip per unit)
-    float bi[3][4], bh[3][4];
+    constexpr int NGATE = LSTM ? 4 : 3;
+    float bi[NGATE][4], bh[NGATE][4], cprev[4];
     if (wave < MT) {
 #pragma unroll
-        for (int g = 0; g < 3; ++g)
+        for (int g = 0; g < NGATE; ++g)
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const int u = min(u0 + 4 * kq + c, H - 1);
                 bi[g][c] = bih[g * H + u];
                 bh[g][c] = bhh[g * H + u];
             }
+        if constexpr (LSTM) {
+            const float* crow = cell.cp + (int64_t)min(m0 + 16 * wave + r16, M - 1) * cell.ldc;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) cprev[c] = crow[min(u0 + 4 * kq + c, H - 1)];
+        }
     }
     __syncthreads();
     SKG_STAMP(4);
     if (wave < MT) {
         // lane holds units u0 + 4 kq .. +3 of batch row m0 + 16 wave + r16; k halves added low + high
         const int m = m0 + 16 * wave + r16;
-        f32x4 pre[6];
+        if constexpr (LSTM) {
+            f32x4 pre[4];   // gate q: the three thirds of its k range (waves q, 4 + q, 8 + q)
 #pragma unroll
-        for (int q = 0; q < 6; ++q)
-            pre[q] = *reinterpret_cast<const f32x4*>(&part[q][wave][lane][0]) +
-                     *reinterpret_cast<const f32x4*>(&part[6 + q][wave][lane][0]);
-        const float* hold = Xs + (16 * wave + r16) * Kp + Inp;
+            for (int q = 0; q < 4; ++q)
+                pre[q] = (*reinterpret_cast<const f32x4*>(&part[q][wave][lane][0]) +
+                          *reinterpret_cast<const f32x4*>(&part[4 + q][wave][lane][0])) +
+                         *reinterpret_cast<const f32x4*>(&part[8 + q][wave][lane][0]);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int u = u0 + 4 * kq + c;
-            if (m < M && u < H) {
-                // same association as the unfused path: (x W^T + b_ih) + (h W^T + b_hh)
-                const float r = sk_sigm((pre[0][c] + bi[0][c]) + (pre[1][c] + bh[0][c]));
-                const float z = sk_sigm((pre[2][c] + bi[1][c]) + (pre[3][c] + bh[1][c]));
-                const float n = tanhf((pre[4][c] + bi[2][c]) + r * (pre[5][c] + bh[2][c]));
-                Hn[(int64_t)m * ldo + u] = (1.f - z) * n + z * hold[u];
+            for (int c = 0; c < 4; ++c) {
+                const int u = u0 + 4 * kq + c;
+                if (m < M && u < H) {
+                    const float gi_ = sk_sigm(pre[0][c] + (bi[0][c] + bh[0][c]));
+                    const float gf = sk_sigm(pre[1][c] + (bi[1][c] + bh[1][c]));
+                    const float gg = tanhf(pre[2][c] + (bi[2][c] + bh[2][c]));
+                    const float go = sk_sigm(pre[3][c] + (bi[3][c] + bh[3][c]));
+                    const float cn = gf * cprev[c] + gi_ * gg;
+                    cell.cn[(int64_t)m * cell.ldc + u] = cn;
+                    Hn[(int64_t)m * ldo + u] = go * tanhf(cn);
+                }
+            }
+        } else {
+            f32x4 pre[6];
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                pre[q] = *reinterpret_cast<const f32x4*>(&part[q][wave][lane][0]) +
+                         *reinterpret_cast<const f32x4*>(&part[6 + q][wave][lane][0]);
+            const float* hold = Xs + (16 * wave + r16) * Kp + Inp;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int u = u0 + 4 * kq + c;
+                if (m < M && u < H) {
+                    // same association as the unfused path: (x W^T + b_ih) + (h W^T + b_hh)
+                    const float r = sk_sigm((pre[0][c] + bi[0][c]) + (pre[1][c] + bh[0][c]));
+                    const float z = sk_sigm((pre[2][c] + bi[1][c]) + (pre[3][c] + bh[1][c]));
+                    const float n = tanhf((pre[4][c] + bi[2][c]) + r * (pre[5][c] + bh[2][c]));
+                    Hn[(int64_t)m * ldo + u] = (1.f - z) * n + z * hold[u];
+                }
             }
         }
     }
@@ -810,18 +859,23 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
 namespace {
 int skg_launch(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H, const float* Wih,
                int64_t ldi, const float* Whh, int64_t ldhh, const float* bih, const float* bhh, int M, float* Hnew,
-               int64_t ldo, const SkgPick* pick, hipStream_t s) {
+               int64_t ldo, const SkgPick* pick, hipStream_t s, const SkgCell* lstm = nullptr) {
     const int Kp = ((In + 15) & ~15) + padded_k(H);
+    const SkgCell cell = lstm ? *lstm : SkgCell{};
     const int n_ub = (H + 15) / 16, grid_x = ((n_ub + 7) / 8) * 8;
     const SkgPick pk = pick ? *pick : SkgPick{};
-#define SKG_LAUNCH(MT, PICK)                                                                                        \
+#define SKG_LAUNCH_C(MT, PICK, LSTM)                                                                                \
     do {                                                                                                            \
         const int lds = 16 * MT * Kp * 4 + 16, m_chunks = (M + 16 * MT - 1) / (16 * MT);                            \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT, PICK>),                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_gru_kernel<MT, PICK, LSTM>),                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                 \
-        hipLaunchKernelGGL((skinny_gru_kernel<MT, PICK>), dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, X,    \
-                           ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub, m_chunks, \
-                           pk);                                                                                     \
+        hipLaunchKernelGGL((skinny_gru_kernel<MT, PICK, LSTM>), dim3(grid_x * m_chunks), dim3(SKG_THREADS), lds, s, \
+                           X, ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Kp, Hnew, ldo, n_ub,        \
+                           m_chunks, pk, cell);                                                                     \
+    } while (0)
+#define SKG_LAUNCH(MT, PICK)                                                                                        \
+    do {                                                                                                            \
+        if (lstm) SKG_LAUNCH_C(MT, PICK, true); else SKG_LAUNCH_C(MT, PICK, false);                                 \
     } while (0)
     // The step is bound by the fp32 MFMA rate of the CUs it occupies, not by the weight stream (a few MB from the
     // Infinity Cache): one 16-row tile per workgroup spreads it over twice the CUs.  Two tiles per workgroup
@@ -835,6 +889,7 @@ int skg_launch(const float* X, int64_t ldx, int In, const float* Hprev, int64_t 
         return DSSVAE_ETOOBIG;
     }
 #undef SKG_LAUNCH
+#undef SKG_LAUNCH_C
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }
@@ -879,4 +934,52 @@ extern "C" int dssvae_skinny_gru_step_pick(const float* part_max, const int64_t*
     pk.xout = x_out; pk.ldxo = ldxo;
     return skg_launch(nullptr, 0, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Hnew, ldo, &pk,
                       (hipStream_t)stream);
+}
+
+// ---- the same two entry points for the LSTM cell (weights [4H, .], gate order i, f, g, o) ------------------------
+namespace {
+int skl_check(const float* Cprev, float* Cnew, int64_t ldc, int H) {
+    if (!Cprev || !Cnew || ldc < H) return DSSVAE_EINVAL;
+    return DSSVAE_OK;
+}
+}  // namespace
+
+extern "C" int dssvae_skinny_lstm_step(const float* X, int64_t ldx, int In, const float* Hprev, int64_t ldh, int H,
+                                       const float* Cprev, float* Cnew, int64_t ldc, const float* Wih, int64_t ldi,
+                                       const float* Whh, int64_t ldhh, const float* bih, const float* bhh, int M,
+                                       float* Hnew, int64_t ldo, void* stream) {
+    if (!X || ldx < In) return DSSVAE_EINVAL;
+    int e = skg_check(Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, In, Hnew, ldo);
+    if (e == DSSVAE_OK || e == DSSVAE_ETOOBIG) {
+        const int e2 = skl_check(Cprev, Cnew, ldc, H);
+        if (e2 != DSSVAE_OK) e = e2;
+    }
+    if (e != DSSVAE_OK) return e;
+    if ((ldx % 4) || !aligned16(X)) return DSSVAE_ETOOBIG;
+    const SkgCell cell{Cprev, Cnew, ldc};
+    return skg_launch(X, ldx, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Hnew, ldo, nullptr,
+                      (hipStream_t)stream, &cell);
+}
+
+extern "C" int dssvae_skinny_lstm_step_pick(const float* part_max, const int64_t* part_arg, int n_split,
+                                            int64_t* tokens_out, const float* table, int64_t ldt, int In,
+                                            float* x_out, int64_t ldxo, const float* Hprev, int64_t ldh, int H,
+                                            const float* Cprev, float* Cnew, int64_t ldc, const float* Wih,
+                                            int64_t ldi, const float* Whh, int64_t ldhh, const float* bih,
+                                            const float* bhh, int M, float* Hnew, int64_t ldo, void* stream) {
+    if (!part_max || !part_arg || n_split <= 0 || !tokens_out || !table || !x_out || ldt < In || ldxo < In)
+        return DSSVAE_EINVAL;
+    int e = skg_check(Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, In, Hnew, ldo);
+    if (e == DSSVAE_OK || e == DSSVAE_ETOOBIG) {
+        const int e2 = skl_check(Cprev, Cnew, ldc, H);
+        if (e2 != DSSVAE_OK) e = e2;
+    }
+    if (e != DSSVAE_OK) return e;
+    if ((ldt % 4) || (ldxo % 4) || !aligned16(table) || !aligned16(x_out)) return DSSVAE_ETOOBIG;
+    SkgPick pk;
+    pk.pm = part_max; pk.pa = part_arg; pk.S = n_split; pk.tok_out = tokens_out; pk.table = table; pk.ldt = ldt;
+    pk.xout = x_out; pk.ldxo = ldxo;
+    const SkgCell cell{Cprev, Cnew, ldc};
+    return skg_launch(nullptr, 0, In, Hprev, ldh, H, Wih, ldi, Whh, ldhh, bih, bhh, M, Hnew, ldo, &pk,
+                      (hipStream_t)stream, &cell);
 }

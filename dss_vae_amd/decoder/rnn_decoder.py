@@ -111,16 +111,17 @@ class RNNDecoder(RNNBase):
         The whole loop is one native call: per step embedding rows, 2 small GEMMs + fused cell per
         layer, projection fused with the arg-max; no host round trip per step."""
         max_length = self.max_length if max_length is None else max_length
-        if self.is_lstm:
-            return self._greedy_lstm(encoder_hidden, max_length)
         params = [self.rnn.layer_params(l) for l in range(self.n_layers)]
+        if self.is_lstm:   # hidden is nn.LSTM's (h_0, c_0): the same native loop on the LSTM cell
+            return ops.greedy_decode(self.embedding.weight, params, self.out.weight, self.out.bias, encoder_hidden[0],
+                                     self.sos_id, max_length, c0=encoder_hidden[1])
         return ops.greedy_decode(self.embedding.weight, params, self.out.weight, self.out.bias, encoder_hidden,
                                  self.sos_id, max_length)
 
-    def _greedy_lstm(self, hidden, max_length):
-        """the greedy loop for the LSTM cell: per step and layer two MFMA products + the fused cell kernel, then the
-        projection fused with the arg-max; enqueued step by step from the host (no device->host traffic), not the
-        one-call native loop of the GRU"""
+    def _greedy_lstm_stepwise(self, hidden, max_length):
+        """the LSTM greedy loop enqueued step by step from the host (per step and layer two MFMA products + the fused
+        cell kernel, then the projection fused with the arg-max): what the native loop replaced; kept as the
+        second opinion of tests/test_generate_gpu.py"""
         h, c = [t.contiguous() for t in hidden[0].unbind(0)], [t.contiguous() for t in hidden[1].unbind(0)]
         B = h[0].size(0)
         tok = torch.full((B,), self.sos_id, device=h[0].device, dtype=torch.int64)

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DSSVAE_LIB") or os.path.join(_HERE, "lib", "libdssvae_hip.so")  # env: development builds
 
-ABI_VERSION = 8  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
+ABI_VERSION = 9  # include/dssvae_hip.h: DSSVAE_ABI_VERSION
 GRU_MAX_INST = 8
 E_TOOBIG = -2
 _ERRORS = {-1: "DSSVAE_EINVAL (rejected argument)", -2: "DSSVAE_ETOOBIG (persistent grid not co-resident)",
@@ -116,6 +116,11 @@ _SIGNATURES = {
                                     _P], _I),
     "dssvae_skinny_argmax": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _P, _P, _P], _I),
     "dssvae_greedy_decode_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
+    "dssvae_greedy_decode_lstm_workspace_bytes": ([_I, _I, _I, _I, _I, _I], _L),
+    "dssvae_greedy_decode_lstm": ([C.POINTER(DecodeParams), _P, _P, _I, _I, _L, _I, _P, _P, _P, _P, _L, _P], _I),
+    "dssvae_skinny_lstm_step": ([_P, _L, _I, _P, _L, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P], _I),
+    "dssvae_skinny_lstm_step_pick": ([_P, _P, _I, _P, _P, _L, _I, _P, _L, _P, _L, _I, _P, _P, _L, _P, _L, _P, _L, _P, _P,
+                                      _I, _P, _L, _P], _I),
     "dssvae_greedy_decode": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P, _L, _P], _I),
     "dssvae_greedy_decode_noalloc": ([C.POINTER(DecodeParams), _P, _I, _I, _L, _I, _P, _P, _P], _I),
     "dssvae_decode_profile": ([_I], _I),

@@ -1680,12 +1680,14 @@ def gru_cell(gi, gh, h):
     return out
 
 
-def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
-    """whole greedy loop in one native call (dssvae_greedy_decode): -> (tokens [max_len,B] int64,
-    h_final [layers,B,H]).  layers: list of (w_ih, w_hh, b_ih, b_hh)."""
+def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len, c0=None):
+    """whole greedy loop in one native call (dssvae_greedy_decode / dssvae_greedy_decode_lstm when c0 is given):
+    -> (tokens [max_len,B] int64, h_final [layers,B,H]) or (tokens, (h_final, c_final)).
+    layers: list of (w_ih, w_hh, b_ih, b_hh)."""
     L.require_cuda(table, w_out, h0)
     n_layers, B, H = h0.shape
     E, V = table.size(1), w_out.size(0)
+    G = 3 if c0 is None else 4
     assert len(layers) == n_layers <= L.DECODE_MAX_LAYERS and w_out.size(1) == H + E
     keep = [_f32(table), _f32(w_out)] + [None if b_out is None else b_out.contiguous()]
     prm = L.DecodeParams()
@@ -1693,14 +1695,15 @@ def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
     for l, ps in enumerate(layers):
         ps = [_f32(t).contiguous() for t in ps]
         keep += ps
-        assert ps[0].shape == (3 * H, E if l == 0 else H) and ps[1].shape == (3 * H, H)
+        assert ps[0].shape == (G * H, E if l == 0 else H) and ps[1].shape == (G * H, H)
         prm.w_ih[l], prm.w_hh[l], prm.b_ih[l], prm.b_hh[l] = (t.data_ptr() for t in ps)
     prm.w_out, prm.ld_out = w_out.data_ptr(), w_out.stride(0)
     prm.b_out = None if keep[2] is None else keep[2].data_ptr()
     prm.E, prm.H, prm.V, prm.n_layers = E, H, V, n_layers
     S = _pick_split(B, V)
     lib = L.load()
-    nbytes = lib.dssvae_greedy_decode_workspace_bytes(B, E, H, n_layers, S, V)
+    size_fn = lib.dssvae_greedy_decode_workspace_bytes if c0 is None else lib.dssvae_greedy_decode_lstm_workspace_bytes
+    nbytes = size_fn(B, E, H, n_layers, S, V)
     if nbytes <= 0:
         raise RuntimeError("dssvae_greedy_decode_workspace_bytes rejected the shape")
     dev = h0.device
@@ -1708,9 +1711,17 @@ def greedy_decode(table, layers, w_out, b_out, h0, sos_id, max_len):
     tokens = torch.empty(max_len, B, device=dev, dtype=torch.int64)
     h_fin = torch.empty(n_layers, B, H, device=dev, dtype=torch.float32)
     h0 = _f32(h0).contiguous()
-    L.check(lib.dssvae_greedy_decode(C.byref(prm), L.ptr(h0), B, int(max_len), int(sos_id), S, L.ptr(tokens),
-                                     L.ptr(h_fin), L.ptr(wsb), nbytes, L.stream()), "dssvae_greedy_decode")
-    return tokens, h_fin
+    if c0 is None:
+        L.check(lib.dssvae_greedy_decode(C.byref(prm), L.ptr(h0), B, int(max_len), int(sos_id), S, L.ptr(tokens),
+                                         L.ptr(h_fin), L.ptr(wsb), nbytes, L.stream()), "dssvae_greedy_decode")
+        return tokens, h_fin
+    assert c0.shape == h0.shape
+    c0 = _f32(c0).contiguous()
+    c_fin = torch.empty_like(h_fin)
+    L.check(lib.dssvae_greedy_decode_lstm(C.byref(prm), L.ptr(h0), L.ptr(c0), B, int(max_len), int(sos_id), S,
+                                          L.ptr(tokens), L.ptr(h_fin), L.ptr(c_fin), L.ptr(wsb), nbytes, L.stream()),
+            "dssvae_greedy_decode_lstm")
+    return tokens, (h_fin, c_fin)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 8 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table */
+#define DSSVAE_ABI_VERSION 9 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table.  9: + dssvae_skinny_lstm_step / _pick, dssvae_greedy_decode_lstm (+ _workspace_bytes) */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -406,6 +406,20 @@ int dssvae_skinny_gru_step_pick(const float* part_max, const int64_t* part_arg, 
                                 const float* Hprev, int64_t ldh, int H, const float* Wih, int64_t ldi,
                                 const float* Whh, int64_t ldhh, const float* bih, const float* bhh, int M,
                                 float* Hnew, int64_t ldo, void* stream);
+/* The two cell-step launches for nn.LSTM decoders (RNNBase's rnn_cell = "lstm": networks/rnn_base.py:32-36,
+ * decoder/rnn_decoder.py:43,65 in the greedy loop :160-168): (h_new, c_new) = LSTMCell(x, (h, c)) with weights
+ * [4H, In] / [4H, H], gate order i, f, g, o.  c_new may alias c_prev (row stride ldc); h_new must not alias h_prev.
+ * Same ranges and error codes as dssvae_skinny_gru_step (the caller's fallback: two dssvae_skinny_linear /
+ * dssvae_gemm_f32 products + dssvae_lstm_step_fwd). */
+int dssvae_skinny_lstm_step(const float* X, int64_t ldx, int In, const float* h_prev, int64_t ldh, int H,
+                            const float* c_prev, float* c_new, int64_t ldc, const float* w_ih, int64_t ld_ih,
+                            const float* w_hh, int64_t ld_hh, const float* b_ih, const float* b_hh, int M,
+                            float* h_new, int64_t ldo, void* stream);
+int dssvae_skinny_lstm_step_pick(const float* part_max, const int64_t* part_arg, int n_split, int64_t* tokens_out,
+                                 const float* table, int64_t ldt, int In, float* x_out, int64_t ldxo,
+                                 const float* Hprev, int64_t ldh, int H, const float* c_prev, float* c_new,
+                                 int64_t ldc, const float* Wih, int64_t ldi, const float* Whh, int64_t ldhh,
+                                 const float* bih, const float* bhh, int M, float* Hnew, int64_t ldo, void* stream);
 int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* part_max,
                          float* part_sum, int64_t* part_arg, void* stream);
@@ -423,8 +437,8 @@ int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, 
 #define DSSVAE_DECODE_MAX_LAYERS 4
 typedef struct {
     const float* embedding; int64_t ld_embedding; int64_t n_embeddings;   /* [n_embeddings, E] */
-    const float* w_ih[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, E] for layer 0, [3H, H] above */
-    const float* w_hh[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, H] */
+    const float* w_ih[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, E] for layer 0, [3H, H] above ([4H, .] for the LSTM loop) */
+    const float* w_hh[DSSVAE_DECODE_MAX_LAYERS];   /* [3H, H] ([4H, H]) */
     const float* b_ih[DSSVAE_DECODE_MAX_LAYERS];
     const float* b_hh[DSSVAE_DECODE_MAX_LAYERS];
     const float* w_out; int64_t ld_out; const float* b_out;                /* [V, H+E], [V] or NULL */
@@ -434,6 +448,13 @@ int64_t dssvae_greedy_decode_workspace_bytes(int B, int E, int H, int n_layers, 
 int dssvae_greedy_decode(const dssvae_decode_params* params, const float* h0, int B, int max_len,
                          int64_t sos_id, int n_split, int64_t* tokens, float* h_final, void* workspace,
                          int64_t workspace_bytes, void* stream);
+/* The same loop for an nn.LSTM decoder (rnn_cell = "lstm": decoder/rnn_decoder.py:43,65,160-168): params' w_ih / w_hh
+ * are [4H, .] (gate order i, f, g, o), the state is the pair (h0, c0) [n_layers,B,H] each; h_final / c_final may be
+ * NULL.  workspace: dssvae_greedy_decode_lstm_workspace_bytes(...) bytes, 16-B aligned. */
+int64_t dssvae_greedy_decode_lstm_workspace_bytes(int B, int E, int H, int n_layers, int n_split, int V);
+int dssvae_greedy_decode_lstm(const dssvae_decode_params* params, const float* h0, const float* c0, int B,
+                              int max_len, int64_t sos_id, int n_split, int64_t* tokens, float* h_final,
+                              float* c_final, void* workspace, int64_t workspace_bytes, void* stream);
 /* Live timing of the loop's dominant launch (projection + arg-max over the vocabulary) for the roofline report: arm
  * = 1 brackets every such launch with HIP events on the launch stream, arm = 0 stops; _read waits for the events and
  * returns their summed duration and count.  No reference counterpart (measurement only; not thread-safe). */

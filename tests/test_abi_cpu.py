@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(so, name), "missing export: " + name
     assert sorted(lib.EXPORTS) == declared_symbols(), "lib.py binding table out of sync with the header"
-    assert so.dssvae_abi_version() == 8
+    assert so.dssvae_abi_version() == 9
 
 
 def test_ops_refuse_cpu_tensors():

@@ -610,6 +610,109 @@ def test_skinny_gru_step_picks_its_tokens(M, In, H, S):
     close(out, want, rtol=1e-4, atol=1e-5, what="picking cell step")
 
 
+def _lstm_cell64(x, h, c, wih, whh, bih, bhh):
+    cell = torch.nn.LSTMCell(x.size(1), h.size(1)).double()
+    with torch.no_grad():
+        cell.weight_ih.copy_(wih), cell.weight_hh.copy_(whh), cell.bias_ih.copy_(bih), cell.bias_hh.copy_(bhh)
+        return cell(x.double(), (h.double(), c.double()))
+
+
+@pytest.mark.parametrize("M,In,H", [(1, 4, 4), (50, 300, 600), (33, 12, 20), (128, 512, 100), (7, 100, 36),
+                                    (50, 768, 768), (100, 300, 1000), (128, 64, 1024), (50, 16, 8)])
+def test_skinny_lstm_step(M, In, H):
+    """fused decode cell step for nn.LSTM decoders (one launch; c updated in place) vs nn.LSTMCell in fp64"""
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    x, h, c = rnd(M, In, seed=1), rnd(M, H, seed=2), rnd(M, H, seed=7)
+    wih, whh = rnd(4 * H, In, seed=3, scale=0.3), rnd(4 * H, H, seed=4, scale=0.3)
+    bih, bhh = rnd(4 * H, seed=5), rnd(4 * H, seed=6)
+    want_h, want_c = _lstm_cell64(x, h, c, wih, whh, bih, bhh)
+    d = [t.to(DEV) for t in (x, h, wih, whh, bih, bhh)]
+    cd = c.to(DEV)
+    out = torch.full((M, H), float("nan"), device=DEV)
+    L.check(lib.dssvae_skinny_lstm_step(L.ptr(d[0]), In, In, L.ptr(d[1]), H, H, L.ptr(cd), L.ptr(cd), H, L.ptr(d[2]), In,
+                                        L.ptr(d[3]), H, L.ptr(d[4]), L.ptr(d[5]), M, L.ptr(out), H, L.stream()),
+            "skinny_lstm_step")
+    close(out, want_h, rtol=1e-4, atol=1e-5, what="fused LSTM step: h")
+    close(cd, want_c, rtol=1e-4, atol=1e-5, what="fused LSTM step: c (in place)")
+    args = [L.ptr(d[0]), In, In, L.ptr(d[1]), H, H, L.ptr(cd), L.ptr(cd), H, L.ptr(d[2]), In, L.ptr(d[3]), H, L.ptr(d[4]),
+            L.ptr(d[5])]
+    assert lib.dssvae_skinny_lstm_step(*args, 129, L.ptr(out), H, L.stream()) == -2
+    assert lib.dssvae_skinny_lstm_step(*args, M, L.ptr(d[1]), H, L.stream()) == -1  # h_new must not alias h_prev
+    args[6] = None
+    assert lib.dssvae_skinny_lstm_step(*args, M, L.ptr(out), H, L.stream()) == -1   # no cell state
+
+
+@pytest.mark.parametrize("M,In,H,S", [(1, 4, 4, 1), (50, 300, 600, 235), (33, 12, 20, 70), (128, 64, 1024, 300)])
+def test_skinny_lstm_step_picks_its_tokens(M, In, H, S):
+    """the LSTM loop's first cell launch of a step: tokens from the previous step's arg-max partials, their embedding
+    rows as x, tokens and rows left behind; vs torch + nn.LSTMCell in fp64"""
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    V = 500
+    g = torch.Generator().manual_seed(M + S)
+    pm = torch.randn(M, S, generator=g)
+    if S > 3:
+        pm[:, S // 2] = pm.max(dim=1).values          # a tie per row: the smaller split must win
+    pa = torch.randint(0, V, (M, S), generator=g)
+    table, h, c = rnd(V, In, seed=1), rnd(M, H, seed=2), rnd(M, H, seed=7)
+    wih, whh = rnd(4 * H, In, seed=3, scale=0.3), rnd(4 * H, H, seed=4, scale=0.3)
+    bih, bhh = rnd(4 * H, seed=5), rnd(4 * H, seed=6)
+    best = torch.tensor([int((pm[m] == pm[m].max()).nonzero()[0]) for m in range(M)])
+    tok = pa[torch.arange(M), best]
+    want_h, want_c = _lstm_cell64(table[tok], h, c, wih, whh, bih, bhh)
+    d = [t.to(DEV) for t in (pm, pa, table, h, wih, whh, bih, bhh)]
+    cd, cn = c.to(DEV), torch.full((M, H), float("nan"), device=DEV)
+    out = torch.full((M, H), float("nan"), device=DEV)
+    tok_out = torch.full((M,), -1, dtype=torch.long, device=DEV)
+    x_out = torch.full((M, In), float("nan"), device=DEV)
+    L.check(lib.dssvae_skinny_lstm_step_pick(L.ptr(d[0]), L.ptr(d[1]), S, L.ptr(tok_out), L.ptr(d[2]), In, In,
+                                             L.ptr(x_out), In, L.ptr(d[3]), H, H, L.ptr(cd), L.ptr(cn), H, L.ptr(d[4]), In,
+                                             L.ptr(d[5]), H, L.ptr(d[6]), L.ptr(d[7]), M, L.ptr(out), H, L.stream()),
+            "skinny_lstm_step_pick")
+    assert torch.equal(tok_out.cpu(), tok)
+    assert torch.equal(x_out.cpu(), table[tok])
+    close(out, want_h, rtol=1e-4, atol=1e-5, what="picking LSTM step: h")
+    close(cn, want_c, rtol=1e-4, atol=1e-5, what="picking LSTM step: c")
+    assert torch.equal(cd.cpu(), c)   # (c_new given its own buffer: c_prev untouched)
+
+
+@pytest.mark.parametrize("B,E,H,V,layers,T", [
+    (5, 12, 20, 97, 1, 6), (50, 300, 600, 3001, 2, 9),
+    (7, 10, 18, 53, 2, 5),         # extents not multiples of 4: two products + dssvae_lstm_step_fwd per layer
+    (50, 300, 1024, 1000, 2, 4),   # fused cell step with 16-row workgroups
+    (200, 64, 128, 500, 1, 4),     # decode batch beyond the skinny kernels' 128 rows
+])
+def test_native_lstm_greedy_decode_loop(B, E, H, V, layers, T):
+    """dssvae_greedy_decode_lstm (whole loop, one call) vs an explicit fp64 loop of the reference's step on nn.LSTM's
+    cell, and vs the loop enqueued step by step from the host (RNNDecoder._greedy_lstm_stepwise's kernels)"""
+    from dss_vae_amd import ops
+    table = rnd(V, E, seed=1, scale=0.5)
+    ps = [(rnd(4 * H, E if l == 0 else H, seed=10 + l, scale=0.2), rnd(4 * H, H, seed=20 + l, scale=0.2),
+           rnd(4 * H, seed=30 + l, scale=0.2), rnd(4 * H, seed=40 + l, scale=0.2)) for l in range(layers)]
+    wo, bo = rnd(V, H + E, seed=2, scale=0.5), rnd(V, seed=3)
+    h0, c0 = rnd(layers, B, H, seed=4), rnd(layers, B, H, seed=5)
+    tok = torch.full((B,), 1, dtype=torch.int64)
+    h, c = [h0[l].double() for l in range(layers)], [c0[l].double() for l in range(layers)]
+    want = []
+    for _ in range(T):
+        e = table.double()[tok]
+        x = e
+        for l, (wih, whh, bih, bhh) in enumerate(ps):
+            gt = x @ wih.double().t() + bih.double() + h[l] @ whh.double().t() + bhh.double()
+            i, f, gg, o = gt.split(H, 1)
+            c[l] = torch.sigmoid(f) * c[l] + torch.sigmoid(i) * torch.tanh(gg)
+            h[l] = torch.sigmoid(o) * torch.tanh(c[l])
+            x = h[l]
+        tok = (torch.cat((x, e), 1) @ wo.double().t() + bo.double()).argmax(1)
+        want.append(tok)
+    got, (hf, cf) = ops.greedy_decode(table.to(DEV), [tuple(t.to(DEV) for t in p) for p in ps], wo.to(DEV), bo.to(DEV),
+                                      h0.to(DEV), 1, T, c0=c0.to(DEV))
+    assert torch.equal(got.cpu(), torch.stack(want, 0))
+    close(hf, torch.stack(h, 0), rtol=1e-4, atol=1e-4, what="h_final")
+    close(cf, torch.stack(c, 0), rtol=1e-4, atol=1e-4, what="c_final")
+
+
 def test_weighted_sums_loss_assembly():
     """out_j = sum_k coef[j][k] * sum(x_k) against fp64; gradients broadcast per input; an input whose live outputs
     all carry a zero coefficient gets None (not zeros); an output that received no gradient contributes nothing"""
