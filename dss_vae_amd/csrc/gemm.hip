@@ -759,6 +759,64 @@ __global__ void ce_onehot_fixup_kernel(const int64_t* __restrict__ target, int64
     }
 }
 
+// The wgrad's last few output columns (904 = 7 x 128 + 8: what is left of [h | e | 1 0 0 0] behind the 128-wide tile
+// columns) without the matrix pipe: C[v, j] (+)= sum_m slab[m, v] * scale[v >> 7][m] * X[m, j], j < nj <= 8.  A 128x64
+// MFMA tile for 8 live columns multiplies 56 columns of padding (0.25 ms per step at the headline shape); this is a
+// stream over the slab -- HBM-bound, 9 flop per element on the vector ALUs -- that needs no LDS while it runs, so it
+// shares the CUs with the wide tiles' launch on a second stream.  A workgroup owns 256 slab columns (a float4 per
+// lane) and a range of rows, its four waves take every fourth row; the partial sums meet in LDS and leave as atomic
+// adds in (v, j) order, 8 consecutive floats per column.
+// (X and the scales staged in LDS per row range, so that the loop issues only the slab loads, measured slower: 0.222 ms
+// against 0.203 at 7936 x 30000 -- 4.7 TB/s of slab; tools/wcols_bench.py)
+constexpr int WCOLS_NJ = 8;
+__global__ __launch_bounds__(256) void ce_wgrad_cols_kernel(const float* __restrict__ slab, int64_t ldl, int rows,
+                                                            int cols, const float* __restrict__ scale, int64_t ld_scale,
+                                                            const float* __restrict__ X, int64_t ldx, int nj,
+                                                            float* __restrict__ C, int64_t ldc, int rows_per_split) {
+    __shared__ float red[4][256][WCOLS_NJ + 1];   // (+1: the (v, j) read-out below strides by a row)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int vb = blockIdx.x * 256, v0 = vb + 4 * lane;
+    const int vc = min(v0, cols - 4);   // (cols is a multiple of 4: a lane's float4 is all inside or all outside)
+    const int m_lo = blockIdx.y * rows_per_split, m_hi = min(rows, m_lo + rows_per_split);
+    const float* sp = slab + vc;
+    const float* sc = scale + (int64_t)(vc >> 7) * ld_scale;
+    float acc[4][WCOLS_NJ];
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < WCOLS_NJ; ++j) acc[c][j] = 0.f;
+#pragma unroll 4
+    for (int m = m_lo + wave; m < m_hi; m += 4) {
+        const float4 s4 = *reinterpret_cast<const float4*>(sp + (int64_t)m * ldl);
+        const float w = sc[m];
+        const float* xr = X + (int64_t)m * ldx;   // wave-uniform: scalar loads
+        float x[WCOLS_NJ];
+#pragma unroll
+        for (int j = 0; j < WCOLS_NJ; ++j) x[j] = j < nj ? xr[min(j, nj - 1)] : 0.f;
+        const float a[4] = {s4.x * w, s4.y * w, s4.z * w, s4.w * w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int j = 0; j < WCOLS_NJ; ++j) acc[c][j] = fmaf(a[c], x[j], acc[c][j]);
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < WCOLS_NJ; ++j) red[wave][4 * lane + c][j] = acc[c][j];
+    __syncthreads();
+    const int j = threadIdx.x & 7;
+    if (j < nj) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int vl = (threadIdx.x >> 3) + 32 * i, v = vb + vl;
+            if (v < cols) {
+                const float t = (red[0][vl][j] + red[1][vl][j]) + (red[2][vl][j] + red[3][vl][j]);
+                unsafeAtomicAdd(C + (int64_t)v * ldc + j, t);
+            }
+        }
+    }
+}
+
 // ---- grouped STORE: up to DSSVAE_GEMM_MAX_GROUP independent products of one layout in ONE launch ----
 // (the per-direction / per-head GRU projections and weight gradients are 1-3 GFLOP each: alone they
 // cannot fill the chip and pay a launch + a tail each).  C = A.B^T + bias.
@@ -1816,6 +1874,30 @@ extern "C" int dssvae_ce_onehot_fixup(const int64_t* target, int64_t ignore_inde
     if (!dX && !dW) return DSSVAE_OK;
     hipLaunchKernelGGL(ce_onehot_fixup_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, target,
                        ignore_index, g, rows, W_panel, ldw, Kx, dX, lddx, Xc, ldxc, Kw, dW, lddw);
+    DSSVAE_CHECK_LAUNCH();
+    return DSSVAE_OK;
+}
+
+extern "C" int dssvae_ce_wgrad_cols(const float* slab, int64_t ldl, int rows, int cols, const float* scale,
+                                    int64_t ld_scale, const float* X, int64_t ldx, int nj, float* C, int64_t ldc,
+                                    float beta, void* stream) {
+    if (!slab || !scale || !X || !C || rows <= 0 || cols <= 0 || nj <= 0 || ldl < cols || ldx < nj || ldc < nj ||
+        ld_scale < rows)
+        return DSSVAE_EINVAL;
+    if (beta != 0.f && beta != 1.f) return DSSVAE_EINVAL;
+    if (nj > WCOLS_NJ || !aligned16(slab) || (ldl % 4) != 0 || (cols % 4) != 0) return DSSVAE_ETOOBIG;
+    hipStream_t s = (hipStream_t)stream;
+    if (beta == 0.f) {   // the row ranges add their sums atomically
+        const int e = dssvae_zero2d(C, ldc, cols, nj, s);
+        if (e != DSSVAE_OK) return e;
+    }
+    // enough workgroups for a few rounds of the chip, at least 64 rows per wave
+    const int vblocks = (cols + 255) / 256;
+    int splits = (8 * n_cus_cached() + vblocks - 1) / vblocks;
+    splits = max(1, min(splits, (rows + 255) / 256));
+    const int rps = ((rows + splits - 1) / splits + 3) & ~3;
+    hipLaunchKernelGGL(ce_wgrad_cols_kernel, dim3(vblocks, (rows + rps - 1) / rps), dim3(256), 0, s, slab, ldl, rows,
+                       cols, scale, ld_scale, X, ldx, nj, C, ldc, rps);
     DSSVAE_CHECK_LAUNCH();
     return DSSVAE_OK;
 }

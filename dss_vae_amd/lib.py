@@ -76,6 +76,7 @@ _SIGNATURES = {
     "dssvae_linear_lse_fwd_norm": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P, _P, _L, _P], _I),
     "dssvae_lse_combine_tiles": ([_P, _P, _I, _I, _L, _P, _P], _I),
     "dssvae_ce_onehot_fixup": ([_P, _L, _P, _I, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P], _I),
+    "dssvae_ce_wgrad_cols": ([_P, _L, _I, _I, _P, _L, _P, _L, _I, _P, _L, _F, _P], _I),
     "dssvae_gemm_f32_dlogits": ([_P, _L, _I, _I, _P, _L, _I, _P, _L, _P, _L, _I, _F, _P], _I),
     "dssvae_lse_combine": ([_P, _P, _P, _I, _I, _P, _P, _P], _I),
     "dssvae_picked_logit": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _P, _I, _L, _I, _P, _P], _I),

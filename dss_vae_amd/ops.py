@@ -715,6 +715,7 @@ CE_STREAMS = max(1, int(_os.environ.get("DSSVAE_CE_STREAMS", "1")))
 # receive the same one); with this flag every backward verifies it (one device sync each: tests / debugging only)
 FUSE_DLOGITS = _os.environ.get("DSSVAE_FUSE_DLOGITS", "1") != "0"  # 0: separate softmax-grad pass over the slab (A/B)
 CHECK_UNIFORM_UPSTREAM = _os.environ.get("DSSVAE_CHECK_UNIFORM", "0") == "1"
+WGRAD_REM_COLS = _os.environ.get("DSSVAE_WGRAD_REM_COLS", "1") != "0"  # 0: the wgrad's remainder columns stay in the MFMA launch (A/B)
 _SIDE = {}
 
 
@@ -852,11 +853,24 @@ class _LinearCEFn(Function):
                         if wg_done is not None and n_str > 1:
                             st.wait_event(wg_done)
                         if fuse:
-                            # (the last 8 output columns -- 904 = 7 x 128 + 8 -- as a launch of their own on a side
-                            # stream, to fill the wide launch's last round: measured 0.25 ms SLOWER per step, the two
-                            # launches take CUs from each other from the start)
+                            # The last few output columns (904 = 7 x 128 + 8) would cost a 128x64 MFMA tile column for
+                            # 8 live columns (0.25 ms): they go through dssvae_ce_wgrad_cols, a stream over the slab on the
+                            # vector ALUs (0.20 ms), in front of the wide tiles' launch.  On a side stream beside that
+                            # launch either form measured SLOWER per step than in line (the narrow MFMA launch by 0.25 ms,
+                            # the stream by 0.19 ms): the wide launch loses more than the side launch takes.
+                            rem = Kw % 128 if WGRAD_REM_COLS else 0
+                            if 0 < rem <= 8 and Kw > 128:
+                                with _Span("ce_wgrad_cols_kernel", 2.0 * N * rem * rows,
+                                           4.0 * (rows * N + rows * rem + N * rem)):
+                                    L.check(lib.dssvae_ce_wgrad_cols(
+                                        L.ptr(dl), ldd, rows, N, L.ptr(tab), tab.stride(0),
+                                        C.c_void_p(xcat.data_ptr() + 4 * (m0 * xcat.stride(0) + Kw - rem)), xcat.stride(0),
+                                        rem, C.c_void_p(dWp.data_ptr() + 4 * (Kw - rem)), Kw, 0.0 if m0 == 0 else 1.0,
+                                        L.stream()), "dssvae_ce_wgrad_cols")
+                            else:
+                                rem = 0
                             _gemm_dlogits(dl, ldd, rows, N, tab, 1, xcat[m0:m0 + rows], xcat.stride(0), dWp,
-                                          Kw, Kw, 0.0 if m0 == 0 else 1.0)
+                                          Kw, Kw - rem, 0.0 if m0 == 0 else 1.0)
                         else:
                             mm_tn(dl[:, :N], xcat[m0:m0 + rows], out=dWp, beta=0.0 if m0 == 0 else 1.0)
                     if fuse and (need_x or need_w):

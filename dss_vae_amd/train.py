@@ -287,6 +287,15 @@ def train_step(model, optimizer, examples, train_iter, global_batch=None):
     return {k: (v.detach() if isinstance(v, torch.Tensor) else v) for k, v in ret.items()}
 
 
+# Stream-capture mode of the step graphs.  HIP's default ("global") forbids potentially unsafe calls in EVERY thread
+# while any stream captures -- and a process with an RCCL communicator has such a thread: ProcessGroupNCCL's watchdog
+# polls the events of finished collectives with hipEventQuery, which invalidates a capture that happens to be open
+# (hipErrorStreamCaptureInvalidated at the next launch; seen once in ~10 runs of the 1-rank RCCL probe).  The batch
+# prefetch thread's copies are the same kind of call.  "thread_local" checks the capturing thread only; nothing another
+# thread enqueues touches the capture stream (torch's streams are non-blocking: no implicit join with the NULL stream).
+CAPTURE_MODE = os.environ.get("DSSVAE_CAPTURE_MODE", "thread_local")
+
+
 class GraphedTrainer(object):
     """`train_iteration` behind a HIP graph: after `warm` eager steps of a shape signature the whole iteration
     (zero_grad, forward, backward, norm, clip, Adam -- and with `adv_train` the two discriminator steps in front) is
@@ -377,7 +386,7 @@ class GraphedTrainer(object):
         try:
             if not split:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, pool=self.pool, stream=self.stream):
+                with torch.cuda.graph(g, pool=self.pool, stream=self.stream, capture_error_mode=CAPTURE_MODE):
                     rec["ret"] = train_iteration(model, opt, rec["static"], train_iter, self.adv[0], self.adv[1])
                 rec["graphs"] = [g]
             else:
@@ -385,13 +394,13 @@ class GraphedTrainer(object):
                     raise RuntimeError("GraphedTrainer: the 3-pass adversarial iteration under data parallel runs eagerly")
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 opt.buckets_off = True     # hooks only record which parameters fired; nothing is sent under capture
-                with torch.cuda.graph(g1, pool=self.pool, stream=self.stream):
+                with torch.cuda.graph(g1, pool=self.pool, stream=self.stream, capture_error_mode=CAPTURE_MODE):
                     opt.zero_grad("main")
                     rec["ret"] = model.get_loss(rec["static"], train_iter)
                     torch.mean(rec["ret"]["Loss"]).backward()
                 if self.pool is None:
                     self.pool = g1.pool()
-                with torch.cuda.graph(g2, pool=self.pool, stream=self.stream):
+                with torch.cuda.graph(g2, pool=self.pool, stream=self.stream, capture_error_mode=CAPTURE_MODE):
                     opt.step(reduce=False)
                 rec["graphs"] = [g1, g2]
                 rec["fired"] = frozenset(opt.fired)

@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 9 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table.  9: + dssvae_skinny_lstm_step / _pick, dssvae_greedy_decode_lstm (+ _workspace_bytes) */
+#define DSSVAE_ABI_VERSION 9 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table.  9: + dssvae_skinny_lstm_step / _pick, dssvae_greedy_decode_lstm (+ _workspace_bytes), dssvae_ce_wgrad_cols */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -116,6 +116,14 @@ int dssvae_lse_combine_tiles(const float* tile_max, const float* tile_sum, int M
 int dssvae_softmax_grad_inplace(float* X, int64_t ldx, const float* lse, const float* coef, int M, int N,
                                 float* colsum, void* stream);
 
+/* The last few output columns of that weight gradient (`trans_a` form) without the matrix pipe:
+ * C[v, j] (+)= sum_m slab[m, v] * scale[(v >> 7) * ld_scale + m] * X[m, j], v < cols, j < nj <= 8 -- the remainder
+ * of [h | e | 1] behind the 128-wide tile columns (904 = 7 x 128 + 8; decoder/rnn_decoder.py:70-73's `out` Linear in
+ * backward).  A stream over the slab on the vector ALUs (HBM-bound), meant to run on a second stream beside the
+ * MFMA launch of the other columns.  beta 0 or 1.  DSSVAE_ETOOBIG: nj > 8 or the slab's rows are not 16-byte
+ * granules (the caller keeps those columns in dssvae_gemm_f32_dlogits). */
+int dssvae_ce_wgrad_cols(const float* slab, int64_t ldl, int rows, int cols, const float* scale, int64_t ld_scale,
+                         const float* X, int64_t ldx, int nj, float* C, int64_t ldc, float beta, void* stream);
 /* The two consumers of a logits slab with the softmax part of the gradient applied WHILE THE SLAB TILE IS STAGED
  * (no separate pass over the slab, nothing written back): with P[m,n] = coef[m] * exp(logit[m,n] - lse[m])
  *                                                              = slab[m,n] * scale[n / 128][m]   (slab: dssvae_linear_lse_fwd_norm),

@@ -610,6 +610,31 @@ def test_skinny_gru_step_picks_its_tokens(M, In, H, S):
     close(out, want, rtol=1e-4, atol=1e-5, what="picking cell step")
 
 
+@pytest.mark.parametrize("rows,cols,nj,beta", [(300, 1000, 8, 0.0), (50, 260, 4, 0.0), (130, 128, 1, 1.0),
+                                                (2050, 5004, 8, 1.0), (7, 4, 3, 0.0)])
+def test_ce_wgrad_remainder_columns(rows, cols, nj, beta):
+    """dssvae_ce_wgrad_cols: C[v, j] (+)= sum_m slab[m, v] * scale[v >> 7][m] * X[m, j] against fp64; X and C are
+    column ranges of wider matrices, as in the fused CE chain (the last columns of [h | e | 1] / of dW)"""
+    from dss_vae_amd import lib as L
+    lib = L.load()
+    ldl, ldx, ldc, tiles = cols + 4, nj + 12, nj + 20, (cols + 127) // 128
+    slab, scale = rnd(rows, ldl, seed=1), rnd(tiles, rows + 3, seed=2).abs()
+    X, C0 = rnd(rows, ldx, seed=3), rnd(cols, ldc, seed=4)
+    sc_full = scale[:, :rows].t().repeat_interleave(128, dim=1)[:, :cols]          # [rows, cols]
+    want = (slab[:, :cols].double() * sc_full.double()).t() @ X[:, 12:12 + nj].double()
+    if beta:
+        want = want + C0[:, 20:20 + nj].double()
+    d_slab, d_scale, d_X, d_C = slab.to(DEV), scale.to(DEV), X.to(DEV), C0.to(DEV).clone()
+    import ctypes as C
+    L.check(lib.dssvae_ce_wgrad_cols(L.ptr(d_slab), ldl, rows, cols, L.ptr(d_scale), rows + 3,
+                                     C.c_void_p(d_X.data_ptr() + 4 * 12), ldx, nj, C.c_void_p(d_C.data_ptr() + 4 * 20), ldc,
+                                     beta, L.stream()), "dssvae_ce_wgrad_cols")
+    close(d_C[:, 20:20 + nj], want, rtol=1e-4, atol=1e-4 * max(1.0, rows ** 0.5), what="remainder columns")
+    assert torch.equal(d_C[:, :20].cpu(), C0[:, :20])    # nothing outside the nj columns is touched
+    assert lib.dssvae_ce_wgrad_cols(L.ptr(d_slab), ldl, rows, cols, L.ptr(d_scale), rows + 3, L.ptr(d_X), ldx, 9,
+                                    L.ptr(d_C), ldc, 0.0, L.stream()) == -2
+
+
 def _lstm_cell64(x, h, c, wih, whh, bih, bhh):
     cell = torch.nn.LSTMCell(x.size(1), h.size(1)).double()
     with torch.no_grad():

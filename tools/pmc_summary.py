@@ -18,7 +18,7 @@ NAMES = ["gemm_store_kernel", "gemm_group_kernel", "dssvae_zero2d_kernel", "line
          "adam_kernel", "sumsq_kernel", "softmax_grad_kernel", "colsum_kernel", "lse_combine_kernel",
          "picked_logit_kernel", "onehot_sub_kernel", "embed_scatter_kernel", "embed_gather_kernel",
          "reparam_kl_fwd_kernel", "reparam_kl_bwd_kernel", "greedy_decode_kernel", "skinny_kernel<true", "skinny_kernel<false",
-         "skinny_gru_kernel", "skinny_argmax64_kernel", "combine_gather_kernel", "ce_rowscale_kernel", "ce_onehot_fixup_kernel", "ce_count_kernel",
+         "skinny_gru_kernel", "skinny_argmax64_kernel", "combine_gather_kernel", "ce_rowscale_kernel", "ce_wgrad_cols_kernel", "ce_onehot_fixup_kernel", "ce_count_kernel",
          "ce_row_nll_kernel", "ce_group_sum_kernel", "dropout_apply_kernel", "dssvae_zero_many_kernel"]
 PAT = re.compile("|".join(NAMES))
 csv.field_size_limit(1 << 30)
