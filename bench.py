@@ -224,7 +224,7 @@ def generate_bench(a, model, vocab, margs, rank, world, margs_dict=None):
             avg_ms = tot_ms.value / launches.value
             nbytes = 4.0 * V * (H + E)
             group = lib.dssvae_skinny_argmax_rows(bs, V)
-            rows = (bs + group - 1) // group * group
+            rows = lib.dssvae_skinny_argmax_padded_rows(bs, V)   # (eval_bs 50: 48 rows in MFMA tiles + 2 on the vector ALUs)
             flops, flops_padded = 2.0 * bs * V * (H + E), 2.0 * rows * V * (H + E)
             gbs = nbytes / (avg_ms * 1e-3) / 1e9
             tf, tf_padded = flops / (avg_ms * 1e-3) / 1e12, flops_padded / (avg_ms * 1e-3) / 1e12

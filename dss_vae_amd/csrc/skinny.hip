@@ -269,30 +269,41 @@ constexpr int SK64_GC = 8;  // k-groups per register chunk: 8 KB per wave, 128 K
 // One register chunk of the stream: GC k-groups x (4 activation reads from LDS + 16 MFMAs).  FULL = every group of
 // the chunk is inside the pass: no branches at all, so the compiler counts the outstanding weight loads (the prefetch
 // of the next chunk stays in flight: s_waitcnt vmcnt(n > 0)) and moves the LDS reads ahead of the MFMAs that hide them.
-template <bool FULL>
-__device__ __forceinline__ void sk64_chunk(f32x4 (&acc)[SK64_TILES], const f32x4 (&cur)[SK64_GC], const float* xs, int Kp,
-                                           int goff, int n_valid) {
+// TILES 16-row tiles go through the matrix pipe; VR more rows (the one or two left behind the last full tile of a decode
+// batch: rows 48, 49 of the reference's eval_bs = 50) are dot products on the vector ALUs -- the lane's four weights
+// times the row's four activations of the same k, summed over the lane groups at the end -- instead of a fourth MFMA
+// tile that would multiply 14 rows of padding (a quarter of the launch's matrix work).
+template <bool FULL, int TILES, int VR>
+__device__ __forceinline__ void sk64_chunk(f32x4 (&acc)[TILES], float (&pv)[VR > 0 ? VR : 1], const f32x4 (&cur)[SK64_GC],
+                                           const float* xs, const float* xv, int Kp, int goff, int n_valid) {
 #pragma unroll
     for (int i = 0; i < SK64_GC; ++i) {
         if (FULL || i < n_valid) {
-            f32x4 x[SK64_TILES];
+            f32x4 x[TILES];
 #pragma unroll
-            for (int t = 0; t < SK64_TILES; ++t)
+            for (int t = 0; t < TILES; ++t)
                 x[t] = *reinterpret_cast<const f32x4*>(xs + t * 16 * Kp + 16 * (goff + i));
+            f32x4 xr[VR > 0 ? VR : 1];
+#pragma unroll
+            for (int v = 0; v < VR; ++v) xr[v] = *reinterpret_cast<const f32x4*>(xv + v * Kp + 16 * (goff + i));
 #ifdef SK_NO_MFMA   // development: the stream alone (the loaded values are consumed by cheap adds)
 #pragma unroll
-            for (int t = 0; t < SK64_TILES; ++t) acc[t] += cur[i] * x[t];
+            for (int t = 0; t < TILES; ++t) acc[t] += cur[i] * x[t];
 #else
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
-                for (int t = 0; t < SK64_TILES; ++t)
+                for (int t = 0; t < TILES; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(cur[i][j], x[t][j], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int v = 0; v < VR; ++v) pv[v] = fmaf(cur[i][j], xr[v][j], pv[v]);
+            }
 #endif
         }
     }
 }
 
+template <int TILES, int VR>
 __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
     const float* __restrict__ X1, int64_t ld1, int K1, const float* __restrict__ X2, int64_t ld2, int K2,
     const float* __restrict__ W, int64_t ldw, const float* __restrict__ bias, int M, int N, int Kp, int g_per_pass,
@@ -327,10 +338,12 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
         const int k = 16 * min(g, g_hi - 1) + 4 * kq;
         return SK_LOADW(wrow + min(k, K - 4));
     };
-    f32x4 acc[SK64_TILES];
+    f32x4 acc[TILES];
 #pragma unroll
-    for (int t = 0; t < SK64_TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TILES; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float pv[VR > 0 ? VR : 1] = {};
     const float* xs = Xs + r16 * Kp + 4 * kq;
+    const float* xv = Xs + 16 * TILES * Kp + 4 * kq;   // rows 16 TILES .. of the image, the same for the 16 lanes of a group
     const RowImage<SK64_ROWS, 16> img(X1, ld1, K1, X2, ld2, K2, m0, M, Kp);
     for (int g_lo = 0; g_lo < nG; g_lo += g_per_pass) {
         const int g_hi = min(nG, g_lo + g_per_pass);
@@ -358,33 +371,33 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
 #pragma unroll
             for (int i = 0; i < GC; ++i) nxt[i] = loadw(g0 + GC + i, g_hi);
             __builtin_amdgcn_sched_barrier(0);  // the prefetch is issued before the chunk's MFMAs, not after
-            sk64_chunk<true>(acc, cur, xs, Kp, g0 - g_lo, GC);
+            sk64_chunk<true, TILES, VR>(acc, pv, cur, xs, xv, Kp, g0 - g_lo, GC);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < GC; ++i) cur[i] = nxt[i];
         }
-        if (g0 < g_hi) sk64_chunk<false>(acc, cur, xs, Kp, g0 - g_lo, g_hi - g0);
+        if (g0 < g_hi) sk64_chunk<false, TILES, VR>(acc, pv, cur, xs, xv, Kp, g0 - g_lo, g_hi - g0);
     }
 #ifdef SK_PROFILE
-    asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[1]), "v"(acc[2]), "v"(acc[3]));
+    asm volatile("s_nop 0" ::"v"(acc[0]), "v"(acc[TILES - 1]), "v"(pv[0]));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         g_skclk[0] = clock64() - c0;
         g_skclk[1] = wall_clock64() - w0;
     }
 #endif
     // lane holds columns nb..nb+3 of activation rows m0 + 16 t + r16
-    float best_v[SK64_TILES];
-    int best_i[SK64_TILES];
+    float best_v[TILES];
+    int best_i[TILES];
     const int nb = blk * 16 + 4 * kq;
 #pragma unroll
-    for (int t = 0; t < SK64_TILES; ++t) { best_v[t] = SK_NEG; best_i[t] = 0; }
+    for (int t = 0; t < TILES; ++t) { best_v[t] = SK_NEG; best_i[t] = 0; }
     if (active) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (nb + r < N) {
                 const float bv = bias ? bias[nb + r] : 0.f;
 #pragma unroll
-                for (int t = 0; t < SK64_TILES; ++t) {
+                for (int t = 0; t < TILES; ++t) {
                     const float v = acc[t][r] + bv;
                     if (v > best_v[t]) { best_v[t] = v; best_i[t] = nb + r; }
                 }
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
     }
     // best over the 4 lane groups of the wave (ties: the smaller column), then over the 8 waves
 #pragma unroll
-    for (int t = 0; t < SK64_TILES; ++t) {
+    for (int t = 0; t < TILES; ++t) {
         float v = best_v[t];
         int ix = best_i[t];
 #pragma unroll
@@ -403,6 +416,25 @@ __global__ __launch_bounds__(SK_THREADS) void skinny_argmax64_kernel(
             if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
         }
         if (kq == 0) { red_v[wave][t * 16 + r16] = v; red_i[wave][t * 16 + r16] = ix; }
+    }
+    // the vector-ALU rows: a lane group holds a quarter of every k group's products of column blk * 16 + r16; summed
+    // over the four groups every lane has the column's logit, then the best of the wave's 16 columns
+#pragma unroll
+    for (int q = 0; q < VR; ++q) {
+        float p = pv[q];
+        p += __shfl_xor(p, 16, 64);
+        p += __shfl_xor(p, 32, 64);
+        const int col = blk * 16 + r16;
+        const bool ok = active && col < N;
+        float v = ok ? p + (bias ? bias[min(col, N - 1)] : 0.f) : SK_NEG;
+        int ix = ok ? col : 0;
+#pragma unroll
+        for (int o = 1; o <= 8; o <<= 1) {
+            const float v2 = __shfl_xor(v, o, 64);
+            const int i2 = __shfl_xor(ix, o, 64);
+            if (v2 > v || (v2 == v && i2 < ix)) { v = v2; ix = i2; }
+        }
+        if (lane == 0) { red_v[wave][16 * TILES + q] = v; red_i[wave][16 * TILES + q] = ix; }
     }
     __syncthreads();
     if (threadIdx.x < SK64_ROWS) {
@@ -822,9 +854,30 @@ extern "C" int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const 
                                 nullptr, nullptr, nullptr, (hipStream_t)stream);
 }
 
+// Which rows of a single 64-row chunk go where: full 16-row tiles on the matrix pipe and, when one or two rows are left
+// behind them, those on the vector ALUs (M = 50: 3 tiles + 2 rows); three or more left-over rows take a tile of their
+// own.  DSSVAE_SKINNY_VALU_ROWS=0: tiles only (A/B).  Launches of several chunks keep four tiles per chunk.
+struct Shape64 { int tiles, vr; };
+Shape64 shape64(int M) {
+    if (M > SK64_ROWS) return {SK64_TILES, 0};
+    static const bool valu = !(getenv("DSSVAE_SKINNY_VALU_ROWS") && atoi(getenv("DSSVAE_SKINNY_VALU_ROWS")) == 0);
+    const int full = M / 16, rem = M % 16;
+    if (rem == 0) return {full, 0};
+    if (valu && rem <= 2 && full >= 2) return {full, rem};
+    return {full + 1, 0};
+}
+
 extern "C" int dssvae_skinny_argmax_rows(int M, int N) {
     if (M <= 0 || N <= 0) return DSSVAE_EINVAL;
     return plan64(M, N, 16).use ? SK64_ROWS : SK_ROWS;
+}
+
+extern "C" int dssvae_skinny_argmax_padded_rows(int M, int N) {
+    if (M <= 0 || N <= 0) return DSSVAE_EINVAL;
+    if (!plan64(M, N, 16).use) return (M + SK_ROWS - 1) / SK_ROWS * SK_ROWS;
+    if (M > SK64_ROWS) return (M + SK64_ROWS - 1) / SK64_ROWS * SK64_ROWS;
+    const Shape64 sh = shape64(M);
+    return 16 * sh.tiles + sh.vr;
 }
 
 extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
@@ -837,11 +890,24 @@ extern "C" int dssvae_skinny_argmax(const float* X1, int64_t ld1, int K1, const 
     const Plan64 p64 = plan64(M, N, K1 + K2);
     if (p64.use) {
         const int lds = SK64_ROWS * p64.Kp * 4 + 16, m_chunks = (M + SK64_ROWS - 1) / SK64_ROWS;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_argmax64_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(skinny_argmax64_kernel, dim3(((p64.n_split + 7) / 8) * 8 * m_chunks), dim3(SK_THREADS), lds,
-                           (hipStream_t)stream, X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N, p64.Kp, p64.g_per_pass,
-                           part_max, part_sum, part_arg, p64.n_split, m_chunks);
+        const Shape64 sh = shape64(M);
+#define SK64_LAUNCH(T, V)                                                                                             \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(skinny_argmax64_kernel<T, V>),                        \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, lds);                                   \
+        hipLaunchKernelGGL((skinny_argmax64_kernel<T, V>), dim3(((p64.n_split + 7) / 8) * 8 * m_chunks),              \
+                           dim3(SK_THREADS), lds, (hipStream_t)stream, X1, ld1, K1, X2, ld2, K2, W, ldw, bias, M, N,  \
+                           p64.Kp, p64.g_per_pass, part_max, part_sum, part_arg, p64.n_split, m_chunks);              \
+    } while (0)
+        switch (sh.tiles * 4 + sh.vr) {
+            case 2 * 4 + 1: SK64_LAUNCH(2, 1); break;
+            case 2 * 4 + 2: SK64_LAUNCH(2, 2); break;
+            case 3 * 4 + 0: SK64_LAUNCH(3, 0); break;
+            case 3 * 4 + 1: SK64_LAUNCH(3, 1); break;
+            case 3 * 4 + 2: SK64_LAUNCH(3, 2); break;
+            default: SK64_LAUNCH(4, 0); break;
+        }
+#undef SK64_LAUNCH
         DSSVAE_CHECK_LAUNCH();
         return DSSVAE_OK;
     }

@@ -111,6 +111,7 @@ _SIGNATURES = {
     "dssvae_skinny_supported": ([_I, _I, _I, _L, _L, _L], _I),
     "dssvae_skinny_argmax_splits": ([_I, _I], _I),
     "dssvae_skinny_argmax_rows": ([_I, _I], _I),
+    "dssvae_skinny_argmax_padded_rows": ([_I, _I], _I),
     "dssvae_skinny_linear": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _I, _I, _P, _L, _P], _I),
     "dssvae_skinny_gru_step": ([_P, _L, _I, _P, _L, _I, _P, _L, _P, _L, _P, _P, _I, _P, _L, _P], _I),
     "dssvae_skinny_gru_step_pick": ([_P, _P, _I, _P, _P, _L, _I, _P, _L, _P, _L, _I, _P, _L, _P, _L, _P, _P, _I, _P, _L,

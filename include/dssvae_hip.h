@@ -28,7 +28,7 @@ extern "C" {
 #define DSSVAE_ETIMEOUT (-3) /* a persistent kernel gave up waiting on a peer (error word set) */
 
 /* library / device probing (no reference counterpart) */
-#define DSSVAE_ABI_VERSION 9 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table.  9: + dssvae_skinny_lstm_step / _pick, dssvae_greedy_decode_lstm (+ _workspace_bytes), dssvae_ce_wgrad_cols */
+#define DSSVAE_ABI_VERSION 9 /* 3: + dssvae_greedy_decode_noalloc; skip_flag in dssvae_adam_step; segments and cell heights in dssvae_gru_*_inst; dssvae_gemm_f32_dlogits; LSTM step.  4: + dssvae_gemm_last_launches, dssvae_gru_error_word; cell / c0 / c_last / dc_last / dc0 in dssvae_gru_*_inst.  5: + dssvae_gru_layout.  6: + dssvae_weighted_sums_fwd / _bwd, dssvae_skinny_gru_step_pick.  7: + dssvae_set_words and the *_dyn entry points (per-step scalars read on the device: HIP-graph replay), dssvae_batch_rows / dssvae_keep_rows (minibatches cut from a device-resident id cache).  8: the training path's logits slab is normalised per 128-column tile: + dssvae_linear_lse_fwd_norm / dssvae_lse_combine_tiles, dssvae_ce_rowscale replaces dssvae_ce_rowinfo, dssvae_gemm_f32_dlogits takes the scale table.  9: + dssvae_skinny_lstm_step / _pick, dssvae_greedy_decode_lstm (+ _workspace_bytes), dssvae_ce_wgrad_cols, dssvae_skinny_argmax_padded_rows */
 int dssvae_abi_version(void);
 int dssvae_device_cus(int* n_cus_host);
 
@@ -390,6 +390,10 @@ int dssvae_skinny_supported(int M, int K1, int K2, int64_t ld1, int64_t ld2, int
  * 64 (skinny_argmax64_kernel: decode batches above 32 rows over a vocabulary large enough to give every CU a workgroup).
  * The MFMA work of a launch is the decode batch padded to a multiple of it.  No reference counterpart. */
 int dssvae_skinny_argmax_rows(int M, int N);
+/* Rows a launch of dssvae_skinny_argmax computes for a decode batch of M: with the 64-row kernel and one row chunk, the
+ * full 16-row MFMA tiles plus one or two left-over rows on the vector ALUs (M = 50: 48 + 2 = 50), else M rounded up to
+ * 16 (three or more left-over rows) / to the kernel's row group.  No reference counterpart (bench.py's padded-work figure). */
+int dssvae_skinny_argmax_padded_rows(int M, int N);
 int dssvae_skinny_argmax_splits(int M, int N);
 int dssvae_skinny_linear(const float* X1, int64_t ld1, int K1, const float* X2, int64_t ld2, int K2,
                          const float* W, int64_t ldw, const float* bias, int M, int N, float* C, int64_t ldc,

@@ -515,7 +515,10 @@ def test_native_greedy_decode_loop(B, E, H, V, layers, T):
 
 
 @pytest.mark.parametrize("M,K1,K2,N", [(1, 4, 0, 5), (50, 600, 300, 3001), (33, 300, 0, 1800), (128, 20, 12, 97),
-                                      (64, 600, 300, 30000), (100, 800, 300, 20000)])  # 64-row arg-max (2 k passes; 1 and 2 row chunks)
+                                      (64, 600, 300, 30000), (100, 800, 300, 20000),   # 64-row arg-max (2 k passes; 1 and 2 row chunks)
+                                      # ... with one or two rows behind the last full tile on the vector ALUs, or fewer tiles
+                                      (50, 600, 300, 30000), (49, 600, 300, 30000), (33, 300, 0, 30000), (34, 600, 300, 30000),
+                                      (40, 600, 300, 30000), (51, 300, 300, 30000)])
 def test_skinny_linear_and_argmax(M, K1, K2, N):
     """C-ABI skinny kernels (decode-batch sized M) vs fp64 torch"""
     from dss_vae_amd import lib as L
