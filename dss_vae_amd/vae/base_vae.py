@@ -9,7 +9,7 @@ import torch.nn as nn
 
 from .. import ops
 from ..networks.rnn_base import GLOBAL_SEEDS
-from ..utils.nn_funcs import device, id2word, kl_anneal_function, to_input_variable, unk_replace, wd_anneal_function
+from ..utils.nn_funcs import device, kl_anneal_function, rows_to_sentences, to_input_variable, unk_replace, wd_anneal_function
 
 
 class Lengths(list):
@@ -211,11 +211,7 @@ class BaseVAE(nn.Module):
 
     def _to_sentences(self, host_tokens, done):
         done.synchronize()
-        out = []
-        for hyp in host_tokens.tolist():
-            words = id2word(hyp, self.vocab.src)
-            out.append([[words], [len(words)]])
-        return out
+        return rows_to_sentences(host_tokens.numpy(), self.vocab.src)
 
     unsupervised_generating = generating
 
@@ -245,12 +241,7 @@ class BaseVAE(nn.Module):
         return self.decoder.greedy_tokens(h0)[0]
 
     def decode_to_sentence(self, ret):
-        toks = self.decode_tokens(ret).t().tolist()
-        out = []
-        for hyp in toks:
-            res = id2word(hyp, self.vocab.src)
-            out.append([[res], [len(res)]])
-        return out
+        return rows_to_sentences(self.decode_tokens(ret).t().cpu().numpy(), self.vocab.src)
 
     GRAPH_SAFE = False  # True: one training step of the class can be captured into a HIP graph (train.GraphedTrainer)
 

@@ -13,7 +13,7 @@ from ..decoder.rnn_decoder import RNNDecoder, score_many
 from ..encoder.rnn_encoder import RNNEncoder, encode_many
 from ..networks.bridger import MLPBridger
 from ..networks.rnn_base import GLOBAL_SEEDS
-from ..utils.nn_funcs import id2word, wd_anneal_function
+from ..utils.nn_funcs import rows_to_sentences, wd_anneal_function
 from .base_vae import BaseVAE, Linear
 
 
@@ -174,12 +174,7 @@ class TwoEncoderVAE(BaseVAE):
         return ret
 
     def predict_syntax(self, hidden, predictor):
-        toks = predictor.predict(hidden).t().tolist()
-        out = []
-        for hyp in toks:
-            res = id2word(hyp, self.vocab.tgt)
-            out.append([[res], [len(res)]])
-        return out
+        return rows_to_sentences(predictor.predict(hidden).t().cpu().numpy(), self.vocab.tgt)
 
     def conditional_generating(self, condition="sem", examples=None):
         ret = self.hidden_to_latent(self.encode_to_hidden(examples), is_sampling=True)
@@ -194,13 +189,23 @@ class TwoEncoderVAE(BaseVAE):
         return ret
 
     def _transfer(self, sem_in, syn_ref, predictor):
-        sem_ret = self.hidden_to_latent(self.encode_to_hidden(sem_in), is_sampling=self.training)
-        syn_ret = self.hidden_to_latent(self.encode_to_hidden(syn_ref, need_sort=True), is_sampling=self.training)
-        sem_ret, syn_ret = self.latent_for_init(ret=sem_ret), self.latent_for_init(ret=syn_ret)
-        ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
+        if not self.training and isinstance(sem_in, list) and isinstance(syn_ref, list) and \
+                os.environ.get("DSSVAE_TRANSFER_MERGE", "1") != "0":
+            # evaluation: nothing is sampled and every row is encoded on its own (packed lengths), so the two inputs
+            # go through the encoders, the latent heads and the init layers as ONE batch -- the front of a pair batch
+            # is ~40 small launches per input that the host, not the GPU, takes its time over
+            n1 = len(sem_in)
+            both = self.latent_for_init(self.hidden_to_latent(self.encode_to_hidden(sem_in + syn_ref), is_sampling=False))
+            ret = self.latent_for_init(dict(sem_z=both["sem_z"][:n1], syn_z=both["syn_z"][n1:]))
+            h_ori, h_ref = both["syn_hidden"][:, :n1].contiguous(), both["syn_hidden"][:, n1:].contiguous()
+        else:
+            sem_ret = self.hidden_to_latent(self.encode_to_hidden(sem_in), is_sampling=self.training)
+            syn_ret = self.hidden_to_latent(self.encode_to_hidden(syn_ref, need_sort=True), is_sampling=self.training)
+            sem_ret, syn_ret = self.latent_for_init(ret=sem_ret), self.latent_for_init(ret=syn_ret)
+            ret = self.latent_for_init(dict(sem_z=sem_ret["sem_z"], syn_z=syn_ret["syn_z"]))
+            h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
         # the sentence tokens leave for pinned host memory behind their decode; they are turned into words
         # below while the GPU runs the tree decodes
-        h_ori, h_ref = sem_ret["syn_hidden"], syn_ret["syn_hidden"]
         n = h_ori.size(1)
         # The tree decodes (100 steps of three launches that fill a fraction of the chip each) run on a side stream
         # BESIDE the sentence decode instead of behind it.
@@ -231,11 +236,7 @@ class TwoEncoderVAE(BaseVAE):
     @staticmethod
     def _words(tokens, vocab):
         """token matrix [B, max_len] -> [[[words], [len]], ...] cut at the first </s>"""
-        out = []
-        for hyp in tokens.tolist():
-            res = id2word(hyp, vocab)
-            out.append([[res], [len(res)]])
-        return out
+        return rows_to_sentences(tokens.cpu().numpy(), vocab)
 
 
 _SIDE = {}

@@ -216,3 +216,28 @@ def test_metrics_tools(tmp_path):
     tools.write_append_result([["y", "z"]], f)
     tools.write_append_result({"k": 1.5}, f)
     assert open(f).read().splitlines() == ["x", "y z", "k:1.500000"]
+
+
+def test_rows_to_words_is_robust_id2word_row_by_row():
+    """the vectorised token-matrix -> words conversion of the decode paths against the reference's per-token loop
+    (utils/nn_funcs.py robust_id2word: cut at the first </s>, <s> and <pad> dropped): random matrices with the
+    special ids anywhere, rows without </s>, </s> in column 0, an empty matrix"""
+    import numpy as np
+    from dss_vae_amd.structs.vocab import VocabEntry
+    from dss_vae_amd.utils.nn_funcs import robust_id2word, rows_to_sentences, rows_to_words
+    v = VocabEntry()
+    for i in range(40):
+        v.add("w%d" % i)
+    rng = np.random.default_rng(0)
+    for L in (1, 7, 35):
+        rows = rng.integers(0, len(v), size=(23, L))
+        rows[0, :] = 5                      # no </s> at all
+        rows[1, 0] = v.eos_id               # empty sentence
+        rows[2, :] = v.pad_id
+        want = [robust_id2word(r, v) for r in rows.tolist()]
+        assert rows_to_words(rows, v) == want
+        assert rows_to_words(rows.tolist(), v) == want
+        assert rows_to_sentences(rows, v) == [[[w], [len(w)]] for w in want]
+    assert rows_to_words(np.zeros((0, 5), dtype=np.int64), v) == []
+    v.add("late")                           # the table follows a vocabulary that grew
+    assert rows_to_words(np.array([[len(v) - 1, v.eos_id]]), v) == [["late"]]
