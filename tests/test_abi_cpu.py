@@ -52,3 +52,16 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(base, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(base, f)
+
+
+def test_argmax_row_plan_is_host_arithmetic():
+    """dssvae_skinny_argmax_padded_rows (no device work: the CU count falls back to 256 without a GPU): full 16-row
+    MFMA tiles + one or two left-over rows on the vector ALUs for a single 64-row chunk, else rounded up"""
+    from dss_vae_amd import lib
+    so = ctypes.CDLL(lib.LIB_PATH)
+    f = so.dssvae_skinny_argmax_padded_rows
+    f.argtypes, f.restype = [ctypes.c_int, ctypes.c_int], ctypes.c_int
+    want = {(50, 30000): 50, (49, 30000): 49, (51, 30000): 64, (40, 30000): 48, (33, 30000): 33, (34, 30000): 34,
+            (35, 30000): 48, (64, 30000): 64, (100, 30000): 128, (20, 30000): 32, (50, 300): 64}
+    assert {k: f(*k) for k in want} == want
+    assert f(0, 5) == -1
